@@ -1,0 +1,790 @@
+// C-ABI host side of libfdmi.so: model state, weight packing, workspaces, the
+// hipGraph-captured reverse-diffusion loop and the measurement hooks.
+// Boundary: include/fdmi.h (each entry point cites the reference function it replaces).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fdmi.h"
+#include "fdmi_kernels.h"
+
+using namespace fdmi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(FD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                          \
+  } while (0)
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct LayerDev {
+  float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
+  float *wo = nullptr, *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr;
+  float *wi = nullptr, *bi = nullptr, *wd = nullptr, *bd = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+enum KClass {
+  KC_EMBED = 0, KC_GEMM_QKV, KC_ATTN, KC_GEMM_OUT, KC_LN1, KC_GEMM_UP, KC_GEMM_DOWN, KC_LN2, KC_GEMM_HEAD,
+  KC_HEAD_UPDATE, KC_ADVANCE, KC_COUNT
+};
+const char* const kClassName[KC_COUNT] = {
+    "embed_ln_time", "gemm_qkv", "attention", "gemm_attn_out", "layernorm_attn", "gemm_ffn_up",
+    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance"};
+
+struct Workspace {
+  int B = 0, L = 0;
+  float *x = nullptr, *eps = nullptr, *h = nullptr, *qkv = nullptr, *ctx = nullptr, *a = nullptr, *tmp = nullptr,
+        *g = nullptr, *z = nullptr;
+  int* lens = nullptr;
+  int* t_dev = nullptr;
+  UpdateDyn* dyn = nullptr;
+  hipGraphExec_t graph = nullptr;
+  int graph_fuse_ln = -1;
+  void release() {
+    if (graph) (void)hipGraphExecDestroy(graph);
+    graph = nullptr;
+    for (void* p : {(void*)x, (void*)eps, (void*)h, (void*)qkv, (void*)ctx, (void*)a, (void*)tmp, (void*)g, (void*)z,
+                    (void*)lens, (void*)t_dev, (void*)dyn})
+      if (p) (void)hipFree(p);
+    *this = Workspace();
+  }
+};
+
+struct PendingEvent {
+  int cls;
+  hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct fd_model {
+  fd_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::map<std::string, HostTensor> host;
+  bool finalized = false;
+  int T = 0;
+  int precision = 0;
+  unsigned angle_mask = 0;
+  // device weights
+  std::vector<void*> allocs;
+  float *w_in = nullptr, *b_in = nullptr, *pos_emb = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+  std::vector<LayerDev> layers;
+  float *hd_w1 = nullptr, *hd_b1 = nullptr, *hd_g = nullptr, *hd_b = nullptr, *hd_w2 = nullptr, *hd_b2 = nullptr;
+  float *coef = nullptr, *time_table = nullptr;
+  // options
+  int fuse_ln = 1;
+  int use_graph = 1;
+  Workspace ws;
+  // profiling
+  int profile_every = 0;
+  double prof_ms[KC_COUNT] = {0};
+  int64_t prof_n[KC_COUNT] = {0};
+  double prof_flops[KC_COUNT] = {0}, prof_bytes[KC_COUNT] = {0};
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int dev_alloc(fd_model* m, float** out, size_t n_floats) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, n_floats * sizeof(float)));
+  m->allocs.push_back(p);
+  *out = static_cast<float*>(p);
+  return FD_OK;
+}
+
+int upload(fd_model* m, float** out, const float* src, size_t n) {
+  int rc = dev_alloc(m, out, n);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*out, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return FD_OK;
+}
+
+void free_weights(fd_model* m) {
+  for (void* p : m->allocs) (void)hipFree(p);
+  m->allocs.clear();
+  m->layers.clear();
+  m->finalized = false;
+}
+
+// expected shape of a state_dict entry; returns false if the name is not a parameter we consume
+bool expected_shape(const fd_config& c, const std::string& name, std::vector<int64_t>* shp, bool* ignored) {
+  *ignored = false;
+  const int64_t d = c.d_model, F = c.n_features, ff = c.d_ff;
+  auto set = [&](std::initializer_list<int64_t> s) { *shp = s; return true; };
+  if (name == "time_embed.W" || name == "embeddings.position_ids") { *ignored = true; return true; }
+  if (name == "inputs_to_hidden_dim.weight") return set({d, F});
+  if (name == "inputs_to_hidden_dim.bias") return set({d});
+  if (name == "embeddings.LayerNorm.weight" || name == "embeddings.LayerNorm.bias") return set({d});
+  if (name == "embeddings.position_embeddings.weight") return set({c.max_pos, d});
+  if (c.decoder == FD_DEC_MLP) {
+    if (name == "token_decoder.dense1.weight") return set({d, d});
+    if (name == "token_decoder.dense1.bias") return set({d});
+    if (name == "token_decoder.layer_norm.weight" || name == "token_decoder.layer_norm.bias") return set({d});
+    if (name == "token_decoder.dense2.weight") return set({F, d});
+    if (name == "token_decoder.dense2.bias") return set({F});
+  } else {
+    if (name == "token_decoder.weight") return set({F, d});
+    if (name == "token_decoder.bias") return set({F});
+  }
+  const std::string pre = "encoder.layer.";
+  if (name.compare(0, pre.size(), pre) == 0) {
+    size_t dot = name.find('.', pre.size());
+    if (dot == std::string::npos) return false;
+    int li = atoi(name.substr(pre.size(), dot - pre.size()).c_str());
+    if (li < 0 || li >= c.n_layers) return false;
+    const std::string rest = name.substr(dot + 1);
+    for (const char* p : {"attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"}) {
+      if (rest == std::string(p) + ".weight") return set({d, d});
+      if (rest == std::string(p) + ".bias") return set({d});
+    }
+    if (rest == "attention.self.distance_embedding.weight") return set({2 * (int64_t)c.max_pos - 1, kHeadDim});
+    for (const char* p : {"attention.output.LayerNorm", "output.LayerNorm"}) {
+      if (rest == std::string(p) + ".weight" || rest == std::string(p) + ".bias") return set({d});
+    }
+    if (rest == "intermediate.dense.weight") return set({ff, d});
+    if (rest == "intermediate.dense.bias") return set({ff});
+    if (rest == "output.dense.weight") return set({d, ff});
+    if (rest == "output.dense.bias") return set({d});
+  }
+  return false;
+}
+
+const HostTensor* need(fd_model* m, const std::string& name) {
+  auto it = m->host.find(name);
+  if (it == m->host.end()) {
+    fail(FD_E_MISSING, "weight '%s' was never provided (fd_set_weight)", name.c_str());
+    return nullptr;
+  }
+  return &it->second;
+}
+
+int ensure_ws(fd_model* m, int B, int L) {
+  Workspace& w = m->ws;
+  if (w.B == B && w.L == L) return FD_OK;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  w.release();
+  const fd_config& c = m->cfg;
+  const size_t M = (size_t)B * L, d = c.d_model, F = c.n_features;
+  const size_t gmax = c.d_ff > c.d_model ? c.d_ff : c.d_model;
+  auto al = [&](void** p, size_t bytes) -> hipError_t { return hipMalloc(p, bytes); };
+  HIP_TRY(al((void**)&w.x, M * F * 4));
+  HIP_TRY(al((void**)&w.eps, M * F * 4));
+  HIP_TRY(al((void**)&w.z, M * F * 4));
+  HIP_TRY(al((void**)&w.h, M * d * 4));
+  HIP_TRY(al((void**)&w.qkv, M * 3 * d * 4));
+  HIP_TRY(al((void**)&w.ctx, M * d * 4));
+  HIP_TRY(al((void**)&w.a, M * d * 4));
+  HIP_TRY(al((void**)&w.tmp, M * d * 4));
+  HIP_TRY(al((void**)&w.g, M * gmax * 4));
+  HIP_TRY(al((void**)&w.lens, (size_t)B * 4));
+  HIP_TRY(al((void**)&w.t_dev, 16));
+  HIP_TRY(al((void**)&w.dyn, sizeof(UpdateDyn)));
+  w.B = B;
+  w.L = L;
+  // algorithmic work per launch: 2*M*N*K for GEMMs, 6*L*d per token for attention
+  const double Md = (double)M, dd = (double)d, ff = (double)c.d_ff, Ld = (double)L;
+  double* fl = m->prof_flops;
+  double* by = m->prof_bytes;
+  fl[KC_EMBED] = 2 * Md * F * dd;            by[KC_EMBED] = 4 * (Md * F + Md * dd);
+  fl[KC_GEMM_QKV] = 2 * Md * 3 * dd * dd;    by[KC_GEMM_QKV] = 4 * (Md * dd + 3 * dd * dd + Md * 3 * dd);
+  fl[KC_ATTN] = 6 * Ld * dd * Md;            by[KC_ATTN] = 4 * (Md * 3 * dd + Md * dd);
+  fl[KC_GEMM_OUT] = 2 * Md * dd * dd;        by[KC_GEMM_OUT] = 4 * (3 * Md * dd + dd * dd);
+  fl[KC_LN1] = 0;                            by[KC_LN1] = 4 * 2 * Md * dd;
+  fl[KC_GEMM_UP] = 2 * Md * ff * dd;         by[KC_GEMM_UP] = 4 * (Md * dd + ff * dd + Md * ff);
+  fl[KC_GEMM_DOWN] = 2 * Md * ff * dd;       by[KC_GEMM_DOWN] = 4 * (Md * ff + ff * dd + 2 * Md * dd);
+  fl[KC_LN2] = 0;                            by[KC_LN2] = 4 * 2 * Md * dd;
+  fl[KC_GEMM_HEAD] = 2 * Md * dd * dd;       by[KC_GEMM_HEAD] = 4 * (2 * Md * dd + dd * dd);
+  fl[KC_HEAD_UPDATE] = 2 * Md * dd * F;      by[KC_HEAD_UPDATE] = 4 * (Md * dd + 3 * Md * F);
+  fl[KC_ADVANCE] = 0;                        by[KC_ADVANCE] = 4;
+  return FD_OK;
+}
+
+struct StepMode {
+  bool forward_only;   // write eps only (fd_forward)
+  bool use_dyn;        // read per-call values from ws.dyn (sampling loop)
+  bool advance;        // decrement *t_dev at the end
+  bool profile;        // bracket every kernel with events
+  // by-value per-call values when !use_dyn (fd_p_sample_step)
+  const float* noise = nullptr;
+  int t_start = 0;
+  bool no_wrap = false;  // p_sample alone, without the loop's wrap
+};
+
+int prof_begin(fd_model* m, int cls, hipStream_t s, bool on) {
+  if (!on) return FD_OK;
+  hipEvent_t e0, e1;
+  for (hipEvent_t* e : {&e0, &e1}) {
+    if (!m->event_pool.empty()) {
+      *e = m->event_pool.back();
+      m->event_pool.pop_back();
+    } else {
+      HIP_TRY(hipEventCreate(e));
+    }
+  }
+  m->pending.push_back({cls, e0, e1});
+  HIP_TRY(hipEventRecord(e0, s));
+  return FD_OK;
+}
+int prof_end(fd_model* m, hipStream_t s, bool on) {
+  if (!on) return FD_OK;
+  HIP_TRY(hipEventRecord(m->pending.back().e1, s));
+  return FD_OK;
+}
+
+int harvest(fd_model* m) {
+  for (PendingEvent& p : m->pending) {
+    HIP_TRY(hipEventSynchronize(p.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.e0, p.e1));
+    m->prof_ms[p.cls] += ms;
+    m->prof_n[p.cls] += 1;
+    m->event_pool.push_back(p.e0);
+    m->event_pool.push_back(p.e1);
+  }
+  m->pending.clear();
+  return FD_OK;
+}
+
+#define PROF(cls, stmt)                                   \
+  do {                                                    \
+    int rc_ = prof_begin(m, cls, s, mode.profile);        \
+    if (rc_) return rc_;                                  \
+    stmt;                                                 \
+    rc_ = prof_end(m, s, mode.profile);                   \
+    if (rc_) return rc_;                                  \
+  } while (0)
+
+// One reverse-diffusion step = BertForDiffusionBase.forward (modelling.py:384-484) + the
+// p_sample update and wrap (sampling.py:62-75, :119-130), as a fixed kernel sequence.
+int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
+  const fd_config& c = m->cfg;
+  Workspace& w = m->ws;
+  const int B = w.B, L = w.L, M = B * L, d = c.d_model, ff = c.d_ff, F = c.n_features;
+  PROF(KC_EMBED, launch_embed(w.x, m->w_in, m->b_in, m->pos_emb, m->emb_g, m->emb_b, c.ln_eps, m->time_table, w.t_dev,
+                              w.h, B, L, F, d, s));
+  for (int li = 0; li < c.n_layers; ++li) {
+    const LayerDev& lw = m->layers[li];
+    PROF(KC_GEMM_QKV, launch_gemm_f32(EPI_BIAS, w.h, lw.wqkv, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
+    bool ok = true;
+    PROF(KC_ATTN, ok = launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
+    if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by this build (max 128)", L);
+    bool fused = false;
+    if (m->fuse_ln)
+      PROF(KC_GEMM_OUT, fused = launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
+    if (!fused) {
+      if (m->fuse_ln && mode.profile) {  // the attempted launch recorded an empty bracket; drop it
+        PendingEvent p = m->pending.back();
+        m->pending.pop_back();
+        m->event_pool.push_back(p.e0);
+        m->event_pool.push_back(p.e1);
+      }
+      PROF(KC_GEMM_OUT, launch_gemm_f32(EPI_BIAS_RESID, w.ctx, lw.wo, lw.bo, w.h, w.tmp, M, d, d, s));
+      PROF(KC_LN1, launch_layernorm(w.tmp, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, s));
+    }
+    PROF(KC_GEMM_UP, launch_gemm_f32(EPI_BIAS_GELU, w.a, lw.wi, lw.bi, nullptr, w.g, M, ff, d, s));
+    fused = false;
+    if (m->fuse_ln)
+      PROF(KC_GEMM_DOWN, fused = launch_gemm_f32_ln(w.g, lw.wd, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s));
+    if (!fused) {
+      if (m->fuse_ln && mode.profile) {
+        PendingEvent p = m->pending.back();
+        m->pending.pop_back();
+        m->event_pool.push_back(p.e0);
+        m->event_pool.push_back(p.e1);
+      }
+      PROF(KC_GEMM_DOWN, launch_gemm_f32(EPI_BIAS_RESID, w.g, lw.wd, lw.bd, w.a, w.tmp, M, d, ff, s));
+      PROF(KC_LN2, launch_layernorm(w.tmp, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, s));
+    }
+  }
+  UpdateArgs u;
+  memset(&u, 0, sizeof u);
+  if (c.decoder == FD_DEC_MLP) {
+    PROF(KC_GEMM_HEAD, launch_gemm_f32(EPI_BIAS_GELU, w.h, m->hd_w1, m->hd_b1, nullptr, w.g, M, d, d, s));
+    u.g = w.g;
+    u.gamma = m->hd_g;
+    u.beta = m->hd_b;
+    u.do_ln = 1;
+  } else {
+    u.g = w.h;
+    u.do_ln = 0;
+  }
+  u.w2 = m->hd_w2;
+  u.b2 = m->hd_b2;
+  u.x = w.x;
+  u.coef = m->coef;
+  u.t_dev = w.t_dev;
+  u.T = m->T;
+  u.M = M;
+  u.L = L;
+  u.F = F;
+  u.d = d;
+  u.ln_eps = 1e-12f;  // AnglesPredictor(eps=1e-12)  (modelling.py:187,199)
+  u.angle_mask = mode.no_wrap ? 0u : m->angle_mask;
+  if (mode.forward_only) {
+    u.eps_out = w.eps;
+    u.x_out = nullptr;
+  } else {
+    u.eps_out = w.eps;
+    u.x_out = w.x;
+    if (mode.use_dyn) {
+      u.dyn = w.dyn;
+    } else {
+      u.noise = mode.noise;
+      u.noise_stride = 0;
+      u.t_start = mode.t_start;
+    }
+  }
+  if (mode.use_dyn) u.noise_stride = (long long)M * F;
+  PROF(KC_HEAD_UPDATE, launch_head_update(u, s));
+  if (mode.advance) PROF(KC_ADVANCE, launch_step_advance(w.t_dev, s));
+  HIP_TRY(hipGetLastError());
+  return FD_OK;
+}
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void set_dyn_kernel(UpdateDyn* p, UpdateDyn v) { *p = v; }
+
+int set_t(fd_model* m, hipStream_t s, int t) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, m->ws.t_dev, t);
+  HIP_TRY(hipGetLastError());
+  return FD_OK;
+}
+
+int check_shape(fd_model* m, int B, int L, int t) {
+  if (!m) return fail(FD_E_INVALID, "null model");
+  if (!m->finalized) return fail(FD_E_STATE, "fd_finalize has not been called");
+  if (B < 1 || L < 1) return fail(FD_E_INVALID, "B=%d L=%d must be positive", B, L);
+  if (t < 0 || t >= m->T) return fail(FD_E_INVALID, "timestep %d outside [0, %d)", t, m->T);
+  if (m->cfg.pos_type != FD_POS_ABSOLUTE && L > m->cfg.max_pos)
+    return fail(FD_E_INVALID, "L=%d exceeds max_position_embeddings=%d", L, m->cfg.max_pos);
+  if (m->cfg.pos_type == FD_POS_ABSOLUTE && L > m->cfg.max_pos)
+    return fail(FD_E_INVALID, "L=%d exceeds max_position_embeddings=%d", L, m->cfg.max_pos);
+  if (L > 128) return fail(FD_E_UNSUPPORTED, "L=%d: this build tiles attention for L <= 128", L);
+  return FD_OK;
+}
+
+int check_lens(const int32_t* lens, int B, int L) {
+  for (int i = 0; i < B; ++i)
+    if (lens[i] < 1 || lens[i] > L) return fail(FD_E_INVALID, "lens[%d]=%d outside [1, %d]", i, lens[i], L);
+  return FD_OK;
+}
+
+int ensure_graph(fd_model* m) {
+  Workspace& w = m->ws;
+  if (w.graph && w.graph_fuse_ln == m->fuse_ln) return FD_OK;
+  if (w.graph) {
+    (void)hipGraphExecDestroy(w.graph);
+    w.graph = nullptr;
+  }
+  // one eager step first: loads code objects and sets function attributes outside capture
+  int rc = set_t(m, m->stream, 0);
+  if (rc) return rc;
+  StepMode warm{};
+  warm.forward_only = true;
+  rc = run_step(m, m->stream, warm);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  StepMode mode{};
+  mode.use_dyn = true;
+  mode.advance = true;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+  rc = run_step(m, m->stream, mode);
+  hipError_t e = hipStreamEndCapture(m->stream, &graph);
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess) return fail(FD_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&w.graph, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(FD_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  w.graph_fuse_ln = m->fuse_ln;
+  return FD_OK;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" {
+
+int fd_abi_version(void) { return FDMI_ABI_VERSION; }
+
+const char* fd_last_error(void) { return g_err.c_str(); }
+
+int fd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fd_create(const fd_config* cfg, int device_id, fd_model** out) {
+  if (!cfg || !out) return fail(FD_E_INVALID, "null argument");
+  *out = nullptr;
+  const fd_config& c = *cfg;
+  if (c.n_features < 1 || c.n_features > kMaxFeat) return fail(FD_E_INVALID, "n_features=%d outside [1,%d]", c.n_features, kMaxFeat);
+  if (c.n_heads < 1 || c.d_model != c.n_heads * kHeadDim)
+    return fail(FD_E_UNSUPPORTED, "d_model=%d n_heads=%d: attention head size must be %d", c.d_model, c.n_heads, kHeadDim);
+  if (c.d_model > 1024) return fail(FD_E_UNSUPPORTED, "d_model=%d > 1024", c.d_model);
+  if (c.d_ff < 32 || c.d_ff % 32) return fail(FD_E_UNSUPPORTED, "d_ff=%d must be a positive multiple of 32", c.d_ff);
+  if (c.n_layers < 1 || c.max_pos < 1) return fail(FD_E_INVALID, "n_layers=%d max_pos=%d", c.n_layers, c.max_pos);
+  if (c.pos_type == FD_POS_RELATIVE_KEY_QUERY)
+    return fail(FD_E_UNSUPPORTED, "position_embedding_type=relative_key_query is not implemented");
+  if (c.pos_type != FD_POS_ABSOLUTE && c.pos_type != FD_POS_RELATIVE_KEY) return fail(FD_E_INVALID, "pos_type=%d", c.pos_type);
+  if (c.decoder != FD_DEC_MLP && c.decoder != FD_DEC_LINEAR) return fail(FD_E_INVALID, "decoder=%d", c.decoder);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(FD_E_INVALID, "device %d of %d", device_id, ndev);
+  HIP_TRY(hipSetDevice(device_id));
+  fd_model* m = new fd_model();
+  m->cfg = c;
+  m->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete m;
+    return fail(FD_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return FD_OK;
+}
+
+int fd_set_weight(fd_model* m, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+  if (!m || !name || !host_data || (ndim > 0 && !shape)) return fail(FD_E_INVALID, "null argument");
+  std::vector<int64_t> want;
+  bool ignored = false;
+  if (!expected_shape(m->cfg, name, &want, &ignored)) return fail(FD_E_INVALID, "unexpected state_dict entry '%s'", name);
+  if (ignored) return FD_OK;
+  std::vector<int64_t> got(shape, shape + ndim);
+  if (got != want) {
+    std::string a, b;
+    for (auto v : got) a += std::to_string(v) + ",";
+    for (auto v : want) b += std::to_string(v) + ",";
+    return fail(FD_E_INVALID, "'%s': shape [%s] does not match config [%s]", name, a.c_str(), b.c_str());
+  }
+  size_t n = 1;
+  for (auto v : got) n *= (size_t)v;
+  HostTensor& t = m->host[name];
+  t.shape = got;
+  t.data.assign(host_data, host_data + n);
+  m->finalized = false;
+  return FD_OK;
+}
+
+int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, const uint8_t* is_angle, int precision) {
+  if (!m || !coef || !time_table || !is_angle) return fail(FD_E_INVALID, "null argument");
+  if (T < 1) return fail(FD_E_INVALID, "T=%d", T);
+  if (precision != FD_PREC_F32) return fail(FD_E_UNSUPPORTED, "precision mode %d", precision);
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->ws.release();
+  free_weights(m);
+  const fd_config& c = m->cfg;
+  const size_t d = c.d_model, F = c.n_features, ff = c.d_ff;
+#define NEED(var, nm)                         \
+  const HostTensor* var = need(m, nm);        \
+  if (!var) return FD_E_MISSING
+#define UP(dst, t) \
+  if (int rc_ = upload(m, &(dst), (t)->data.data(), (t)->data.size())) return rc_
+  NEED(t_win, "inputs_to_hidden_dim.weight");
+  NEED(t_bin, "inputs_to_hidden_dim.bias");
+  NEED(t_eg, "embeddings.LayerNorm.weight");
+  NEED(t_eb, "embeddings.LayerNorm.bias");
+  UP(m->w_in, t_win);
+  UP(m->b_in, t_bin);
+  UP(m->emb_g, t_eg);
+  UP(m->emb_b, t_eb);
+  m->pos_emb = nullptr;
+  if (c.pos_type == FD_POS_ABSOLUTE) {
+    NEED(t_pe, "embeddings.position_embeddings.weight");
+    UP(m->pos_emb, t_pe);
+  }
+  m->layers.resize(c.n_layers);
+  for (int li = 0; li < c.n_layers; ++li) {
+    const std::string p = "encoder.layer." + std::to_string(li) + ".";
+    LayerDev& lw = m->layers[li];
+    NEED(wq, p + "attention.self.query.weight");
+    NEED(wk, p + "attention.self.key.weight");
+    NEED(wv, p + "attention.self.value.weight");
+    NEED(bq, p + "attention.self.query.bias");
+    NEED(bk, p + "attention.self.key.bias");
+    NEED(bv, p + "attention.self.value.bias");
+    std::vector<float> wqkv, bqkv;  // rows: [query | key | value]  => one N = 3d GEMM
+    wqkv.reserve(3 * d * d);
+    for (const HostTensor* t : {wq, wk, wv}) wqkv.insert(wqkv.end(), t->data.begin(), t->data.end());
+    for (const HostTensor* t : {bq, bk, bv}) bqkv.insert(bqkv.end(), t->data.begin(), t->data.end());
+    if (int rc = upload(m, &lw.wqkv, wqkv.data(), wqkv.size())) return rc;
+    if (int rc = upload(m, &lw.bqkv, bqkv.data(), bqkv.size())) return rc;
+    lw.demb = nullptr;
+    if (c.pos_type == FD_POS_RELATIVE_KEY) {
+      NEED(de, p + "attention.self.distance_embedding.weight");
+      UP(lw.demb, de);
+    }
+    NEED(wo, p + "attention.output.dense.weight");
+    NEED(bo, p + "attention.output.dense.bias");
+    NEED(g1, p + "attention.output.LayerNorm.weight");
+    NEED(b1, p + "attention.output.LayerNorm.bias");
+    NEED(wi, p + "intermediate.dense.weight");
+    NEED(bi, p + "intermediate.dense.bias");
+    NEED(wd, p + "output.dense.weight");
+    NEED(bd, p + "output.dense.bias");
+    NEED(g2, p + "output.LayerNorm.weight");
+    NEED(b2, p + "output.LayerNorm.bias");
+    UP(lw.wo, wo); UP(lw.bo, bo); UP(lw.ln1g, g1); UP(lw.ln1b, b1);
+    UP(lw.wi, wi); UP(lw.bi, bi); UP(lw.wd, wd); UP(lw.bd, bd); UP(lw.ln2g, g2); UP(lw.ln2b, b2);
+  }
+  if (c.decoder == FD_DEC_MLP) {
+    NEED(w1, "token_decoder.dense1.weight");
+    NEED(b1, "token_decoder.dense1.bias");
+    NEED(g, "token_decoder.layer_norm.weight");
+    NEED(b, "token_decoder.layer_norm.bias");
+    NEED(w2, "token_decoder.dense2.weight");
+    NEED(b2, "token_decoder.dense2.bias");
+    UP(m->hd_w1, w1); UP(m->hd_b1, b1); UP(m->hd_g, g); UP(m->hd_b, b); UP(m->hd_w2, w2); UP(m->hd_b2, b2);
+  } else {
+    NEED(w2, "token_decoder.weight");
+    NEED(b2, "token_decoder.bias");
+    UP(m->hd_w2, w2); UP(m->hd_b2, b2);
+  }
+#undef NEED
+#undef UP
+  (void)ff;
+  if (int rc = upload(m, &m->coef, coef, (size_t)4 * T)) return rc;
+  if (int rc = upload(m, &m->time_table, time_table, (size_t)T * d)) return rc;
+  m->angle_mask = 0;
+  for (size_t f = 0; f < F; ++f)
+    if (is_angle[f]) m->angle_mask |= 1u << f;
+  m->T = T;
+  m->precision = precision;
+  m->finalized = true;
+  return FD_OK;
+}
+
+void fd_destroy(fd_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  m->ws.release();
+  free_weights(m);
+  for (PendingEvent& p : m->pending) {
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int fd_set_option(fd_model* m, const char* name, int value) {
+  if (!m || !name) return fail(FD_E_INVALID, "null argument");
+  const std::string n = name;
+  if (n == "fuse_ln") m->fuse_ln = value ? 1 : 0;
+  else if (n == "use_graph") m->use_graph = value ? 1 : 0;
+  else return fail(FD_E_INVALID, "unknown option '%s'", name);
+  return FD_OK;
+}
+
+int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, float* eps_out) {
+  if (int rc = check_shape(m, B, L, t)) return rc;
+  if (!x || !lens || !eps_out) return fail(FD_E_INVALID, "null argument");
+  if (int rc = check_lens(lens, B, L)) return rc;
+  HIP_TRY(hipSetDevice(m->device));
+  if (int rc = ensure_ws(m, B, L)) return rc;
+  Workspace& w = m->ws;
+  const size_t n = (size_t)B * L * m->cfg.n_features;
+  hipStream_t s = m->stream;
+  HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(w.lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  if (int rc = set_t(m, s, t)) return rc;
+  StepMode mode{};
+  mode.forward_only = true;
+  if (int rc = run_step(m, s, mode)) return rc;
+  HIP_TRY(hipMemcpyAsync(eps_out, w.eps, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FD_OK;
+}
+
+int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, const float* z, int wrap,
+                     float* x_out) {
+  if (int rc = check_shape(m, B, L, t)) return rc;
+  if (!x || !lens || !x_out) return fail(FD_E_INVALID, "null argument");
+  if (t > 0 && !z) return fail(FD_E_INVALID, "z is required for t > 0");
+  if (int rc = check_lens(lens, B, L)) return rc;
+  HIP_TRY(hipSetDevice(m->device));
+  if (int rc = ensure_ws(m, B, L)) return rc;
+  Workspace& w = m->ws;
+  const size_t n = (size_t)B * L * m->cfg.n_features;
+  hipStream_t s = m->stream;
+  HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(w.lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  if (z) HIP_TRY(hipMemcpyAsync(w.z, z, n * 4, hipMemcpyHostToDevice, s));
+  if (int rc = set_t(m, s, t)) return rc;
+  StepMode mode{};
+  mode.noise = w.z;
+  mode.t_start = t;
+  mode.no_wrap = !wrap;
+  if (int rc = run_step(m, s, mode)) return rc;
+  HIP_TRY(hipMemcpyAsync(x_out, w.x, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FD_OK;
+}
+
+int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
+                  const void* noise_dev, uint64_t seed, int64_t seq_offset, void* out_dev, int full_history,
+                  void* hip_stream) {
+  if (int rc = check_shape(m, B, L, t_start)) return rc;
+  if (!x_init_dev || !lens_dev || !out_dev) return fail(FD_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  if (int rc = ensure_ws(m, B, L)) return rc;
+  if (m->use_graph)
+    if (int rc = ensure_graph(m)) return rc;
+  Workspace& w = m->ws;
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  const size_t n = (size_t)B * L * m->cfg.n_features;
+  HIP_TRY(hipMemcpyAsync(w.x, x_init_dev, n * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(w.lens, lens_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  UpdateDyn dyn;
+  memset(&dyn, 0, sizeof dyn);
+  dyn.noise = static_cast<const float*>(noise_dev);
+  dyn.hist = full_history ? static_cast<float*>(out_dev) : nullptr;
+  dyn.seed = seed;
+  dyn.seq_offset = seq_offset;
+  dyn.t_start = t_start;
+  hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, s, w.dyn, dyn);
+  if (int rc = set_t(m, s, t_start)) return rc;
+  const int nsteps = t_start + 1;
+  for (int i = 0; i < nsteps; ++i) {
+    const bool prof = m->profile_every > 0 && (i % m->profile_every) == m->profile_every / 2;
+    if (m->use_graph && !prof) {
+      HIP_TRY(hipGraphLaunch(w.graph, s));
+    } else {
+      StepMode mode{};
+      mode.use_dyn = true;
+      mode.advance = true;
+      mode.profile = prof;
+      if (int rc = run_step(m, s, mode)) return rc;
+    }
+  }
+  if (!full_history) HIP_TRY(hipMemcpyAsync(out_dev, w.x, n * 4, hipMemcpyDeviceToDevice, s));
+  return FD_OK;
+}
+
+int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
+              uint64_t seed, float* out, int full_history) {
+  if (int rc = check_shape(m, B, L, t_start)) return rc;
+  if (!x_init || !lens || !out) return fail(FD_E_INVALID, "null argument");
+  if (int rc = check_lens(lens, B, L)) return rc;
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t n = (size_t)B * L * m->cfg.n_features;
+  const size_t nsteps = (size_t)t_start + 1;
+  float *d_x = nullptr, *d_noise = nullptr, *d_out = nullptr;
+  int* d_lens = nullptr;
+  int rc = FD_OK;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_x, (void*)d_noise, (void*)d_out, (void*)d_lens})
+      if (p) (void)hipFree(p);
+  };
+#define TRY_CLEAN(expr)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      cleanup();                                                                           \
+      return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+    }                                                                                      \
+  } while (0)
+  TRY_CLEAN(hipMalloc((void**)&d_x, n * 4));
+  TRY_CLEAN(hipMalloc((void**)&d_lens, (size_t)B * 4));
+  TRY_CLEAN(hipMalloc((void**)&d_out, (full_history ? nsteps : 1) * n * 4));
+  TRY_CLEAN(hipMemcpy(d_x, x_init, n * 4, hipMemcpyHostToDevice));
+  TRY_CLEAN(hipMemcpy(d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice));
+  if (noise) {
+    TRY_CLEAN(hipMalloc((void**)&d_noise, nsteps * n * 4));
+    TRY_CLEAN(hipMemcpy(d_noise, noise, nsteps * n * 4, hipMemcpyHostToDevice));
+  }
+  rc = fd_sample_dev(m, d_x, d_lens, B, L, t_start, d_noise, seed, 0, d_out, full_history, nullptr);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  TRY_CLEAN(hipStreamSynchronize(m->stream));
+  TRY_CLEAN(hipMemcpy(out, d_out, (full_history ? nsteps : 1) * n * 4, hipMemcpyDeviceToHost));
+#undef TRY_CLEAN
+  cleanup();
+  return FD_OK;
+}
+
+int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, int B, int L, void* out_dev,
+                         void* hip_stream) {
+  if (!m || !out_dev) return fail(FD_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  launch_philox_fill(static_cast<float*>(out_dev), seed, t, seq_offset, B, L, m->cfg.n_features, s);
+  HIP_TRY(hipGetLastError());
+  return FD_OK;
+}
+
+int fd_profile_every(fd_model* m, int n) {
+  if (!m || n < 0) return fail(FD_E_INVALID, "bad argument");
+  m->profile_every = n;
+  return FD_OK;
+}
+
+int fd_profile_reset(fd_model* m) {
+  if (!m) return fail(FD_E_INVALID, "null model");
+  if (int rc = harvest(m)) return rc;
+  for (int i = 0; i < KC_COUNT; ++i) {
+    m->prof_ms[i] = 0;
+    m->prof_n[i] = 0;
+  }
+  return FD_OK;
+}
+
+int fd_profile_count(fd_model* m) { return m ? (int)KC_COUNT : 0; }
+
+int fd_profile_get(fd_model* m, int i, const char** name, double* total_ms, int64_t* launches, double* flops_per_launch,
+                   double* bytes_per_launch) {
+  if (!m || i < 0 || i >= KC_COUNT) return fail(FD_E_INVALID, "bad argument");
+  if (int rc = harvest(m)) return rc;
+  if (name) *name = kClassName[i];
+  if (total_ms) *total_ms = m->prof_ms[i];
+  if (launches) *launches = m->prof_n[i];
+  if (flops_per_launch) *flops_per_launch = m->prof_flops[i];
+  if (bytes_per_launch) *bytes_per_launch = m->prof_bytes[i];
+  return FD_OK;
+}
+
+int fd_synchronize(fd_model* m) {
+  if (!m) return fail(FD_E_INVALID, "null model");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return FD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// Multi-head self-attention of HF BertSelfAttention (transformers 4.11.3; called
+// from foldingdiff/modelling.py:473-480) with the additive key mask of
+// modelling.py:450-452 and the relative_key score term the released model uses
+// (config_jsons/cath_full_angles_cosine.json:10):
+//
+//   S[l,r] = ( q_l . k_r + q_l . E[l - r + maxpos - 1] ) / sqrt(32) + (r >= len ? -10000 : 0)
+//   P = softmax_r(S);   ctx[l,:] = sum_r P[l,r] v_r
+//
+// One workgroup per (sequence, head); K, V and the needed band of the distance
+// table E live in LDS; each of the 4 waves owns 32-query row blocks.  All three
+// contractions run on v_mfma_f32_32x32x2_f32 (exact fp32):
+//   * S tiles   32 x 32 :  A = Q rows (registers), B = K rows (LDS)
+//   * R tiles   32 x 32 :  R[l, m] = q_l . E[m] over the 32*(T+1)-wide band of m the
+//                          row block can reach; the Toeplitz skew  S[l,r] += R[l, l-r+c]
+//                          is a same-row cross-lane gather (ds_bpermute), two candidate
+//                          tiles per S tile  => (T+1)/T extra MFMA work instead of 2x.
+//   * softmax in registers: a row lives in one 32-lane half -> xor-shuffle butterflies.
+//   * P goes through a per-wave LDS scratch to become the A operand of P.V.
+// The score matrix never touches HBM (it would be B*H*L^2*4 = 403 MB per layer at C2).
+#include "fdmi_kernels.h"
+
+namespace fdmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KLD = 36;  // padded row stride (floats) of K / E tiles: conflict-free ds_read_b128
+
+template <int T, bool REL>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ demb,
+                                                       const int* __restrict__ lens, float* __restrict__ ctx, int L,
+                                                       int H, int maxpos) {
+  constexpr int LP = 32 * T;   // padded sequence length
+  constexpr int PS = LP + 4;   // row stride of the P scratch
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;                              // [LP][36]
+  float* Vs = Ks + LP * KLD;                     // [LP][32]
+  float* Es = Vs + LP * 32;                      // [2*LP][36]   (REL only)
+  float* Ps = Es + (REL ? 2 * LP * KLD : 0);     // [4 waves][32][PS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * 32, ld = 3 * d;
+  const int len = lens[b];
+  const float* base = qkv + (size_t)b * L * ld + h * 32;
+
+  for (int idx = tid; idx < LP * 8; idx += 256) {
+    const int r = idx >> 3, c4 = idx & 7;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (r < L) {
+      kv = *reinterpret_cast<const float4*>(base + (size_t)r * ld + d + c4 * 4);
+      vv = *reinterpret_cast<const float4*>(base + (size_t)r * ld + 2 * d + c4 * 4);
+    }
+    *reinterpret_cast<float4*>(&Ks[r * KLD + c4 * 4]) = kv;
+    *reinterpret_cast<float4*>(&Vs[r * 32 + c4 * 4]) = vv;
+  }
+  if constexpr (REL) {
+    // Es[e] = E[m_min + e],  m_min = (maxpos-1) - (LP-1); rows outside the table are never
+    // selected for a valid (l, r) pair and are zero filled.
+    const int m_min = (maxpos - 1) - (LP - 1);
+    for (int idx = tid; idx < 2 * LP * 8; idx += 256) {
+      const int e = idx >> 3, c4 = idx & 7, m = e + m_min;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m >= 0 && m <= 2 * (maxpos - 1)) v = *reinterpret_cast<const float4*>(demb + (size_t)m * 32 + c4 * 4);
+      *reinterpret_cast<float4*>(&Es[e * KLD + c4 * 4]) = v;
+    }
+  }
+  __syncthreads();
+
+  float* Pw = Ps + wid * 32 * PS;
+  const int nrb = (L + 31) >> 5;
+  for (int rb = wid; rb < nrb; rb += 4) {
+    const int l0 = rb * 32;
+    // Q fragment: A[i = l31][k = 8g + 4*half + s]
+    f32x4 qa[4];
+    {
+      const int l = l0 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < L) v = *reinterpret_cast<const float4*>(base + (size_t)l * ld + 8 * g + 4 * half);
+        qa[g][0] = v.x; qa[g][1] = v.y; qa[g][2] = v.z; qa[g][3] = v.w;
+      }
+    }
+    f32x16 sacc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[(32 * t + l31) * KLD + 8 * g + 4 * half]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g][s], kb[s], sacc[t], 0, 0, 0);
+      }
+    }
+    if constexpr (REL) {
+      f32x16 racc[T + 1];
+#pragma unroll
+      for (int q = 0; q <= T; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[q][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 eb = *reinterpret_cast<const f32x4*>(&Es[(l0 + 32 * q + l31) * KLD + 8 * g + 4 * half]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) racc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g][s], eb[s], racc[q], 0, 0, 0);
+        }
+      }
+      // R tile q, column j  <->  m = c + l0 - 32*(T-1-q) - 31 + j.  For S tile t (q = T-1-t)
+      // element (li, rj) needs j = li - rj + 31 in [0, 62]: tile q (j < 32) or q+1 (j - 32).
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int q = T - 1 - t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int li = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int delta = li - l31 + 31;
+          const int src = (delta & 31) + 32 * half;
+          const float lo = __shfl(racc[q][r], src);
+          const float hi = __shfl(racc[q + 1][r], src);
+          sacc[t][r] += (delta >= 32) ? hi : lo;
+        }
+      }
+    }
+    // scale, mask, softmax over r (row li lives in this lane's 32-lane half)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int key = 32 * t + l31;
+        float s = sacc[t][r] / 5.65685424949238f;  // / sqrt(attention_head_size)
+        if (key >= len) s += -10000.0f;            // (1 - mask) * -10000   (modelling.py:452)
+        if (key >= L) s = -INFINITY;               // tile padding: not a key at all
+        sacc[t][r] = s;
+        mx = fmaxf(mx, s);
+      }
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float pexp = expf(sacc[t][r] - mx);
+        sacc[t][r] = pexp;
+        sum += pexp;
+      }
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+      const int li = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+      for (int t = 0; t < T; ++t) Pw[li * PS + 32 * t + l31] = sacc[t][r] / sum;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ctx = P V :  A[i = l31][k] = P[l0 + l31][8*g8 + 4*half + s],  B[k][j = l31] = V[k][j]
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll 4
+    for (int g8 = 0; g8 < LP / 8; ++g8) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(&Pw[l31 * PS + 8 * g8 + 4 * half]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float vb = Vs[(8 * g8 + 4 * half + s) * 32 + l31];
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], vb, oacc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int l = l0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (l < L) ctx[((size_t)b * L + l) * d + h * 32 + l31] = oacc[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int T, bool REL>
+static void launch_t(const float* qkv, const float* demb, const int* lens, float* ctx, int B, int L, int H, int maxpos,
+                     hipStream_t s) {
+  constexpr int LP = 32 * T;
+  const size_t smem = sizeof(float) * (LP * KLD + LP * 32 + (REL ? 2 * LP * KLD : 0) + 4 * 32 * (LP + 4));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<T, REL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_f32_kernel<T, REL>), dim3(B * H), dim3(256), smem, s, qkv, demb, lens, ctx, L, H, maxpos);
+}
+
+bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
+                          int maxpos, hipStream_t s) {
+  if (L < 1 || L > 128) return false;
+  const int T = (L + 31) / 32;
+  const bool rel = dist_emb != nullptr;
+#define FD_ATTN_CASE(TT)                                                          \
+  case TT:                                                                        \
+    if (rel) launch_t<TT, true>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);    \
+    else launch_t<TT, false>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);       \
+    break;
+  switch (T) {
+    FD_ATTN_CASE(1)
+    FD_ATTN_CASE(2)
+    FD_ATTN_CASE(3)
+    FD_ATTN_CASE(4)
+  }
+#undef FD_ATTN_CASE
+  return true;
+}
+
+}  // namespace fdmi

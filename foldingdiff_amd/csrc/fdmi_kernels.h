@@ -1,0 +1,92 @@
+// Internal launch interface between the C-ABI host code (api.hip) and the
+// gfx950 kernels.  Not installed; include/fdmi.h is the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdmi {
+
+constexpr int kHeadDim = 32;   // d_model / n_heads, fixed by the MFMA tilings
+constexpr int kMaxFeat = 16;   // F <= 16 (reference feature sets have 3..9)
+
+// ---- epilogues of the token GEMM  C[M,N] = A[M,K] * W[N,K]^T + bias[N] ----
+enum GemmEpilogue {
+  EPI_BIAS = 0,        // QKV projection
+  EPI_BIAS_GELU = 1,   // BertIntermediate / AnglesPredictor.dense1: exact-erf GELU
+  EPI_BIAS_RESID = 2   // BertSelfOutput / BertOutput dense: + residual (LayerNorm follows)
+};
+
+// fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32).  K % 32 == 0; M, N arbitrary.
+void launch_gemm_f32(int epilogue, const float* A, const float* W, const float* bias, const float* resid, float* C,
+                     int M, int N, int K, hipStream_t s);
+
+// Fused GEMM + bias + residual + LayerNorm over full rows (N == 384 or 192):
+//   C = LN(A * W^T + bias + resid) * gamma + beta.   Returns false if (N) has no instantiation.
+bool launch_gemm_f32_ln(const float* A, const float* W, const float* bias, const float* resid, const float* gamma,
+                        const float* beta, float eps, float* C, int M, int N, int K, hipStream_t s);
+
+// y[r,:] = LN(x[r,:]) * gamma + beta, rows of length d (d <= 1024), one wave per row.
+void launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int d,
+                      hipStream_t s);
+
+// K1: h = LN(x W_in^T + b_in (+ pos_emb[l])) * g + b + time_table[*t_dev]
+void launch_embed(const float* x, const float* w_in, const float* b_in, const float* pos_emb /*null unless absolute*/,
+                  const float* gamma, const float* beta, float eps, const float* time_table, const int* t_dev,
+                  float* h, int B, int L, int F, int d, hipStream_t s);
+
+// K4: multi-head self-attention with additive key mask and (optionally) the
+// relative_key score term.  qkv: [B*L, 3d] (q | k | v), ctx: [B*L, d].
+// dist_emb: [2*maxpos-1, 32] of this layer, or null for absolute positions.
+// Returns false when L is beyond what this build tiles (L > 128).
+bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
+                          int maxpos, hipStream_t s);
+
+// K8 tail + K9: per token  y = do_ln ? LN(g)*gamma+beta : g ;  eps = y W2^T + b2 ;
+//   x' = wrap_if_angle( c1[t] * (x - beta[t]*eps / c3[t]) + (t>0 ? sigma[t]*z : 0) )
+// coef: [4][T] (c1, beta, c3, sigma).  t is read from *t_dev.
+// z comes from noise[t][...] when noise != null, else Philox(seed, t, element).
+// Writes eps_out (if non-null), x_out (may alias x), hist[T_hist_row] (if non-null).
+// Per-call values the captured per-step graph must not bake in: they live in a
+// small device struct that the host rewrites before each sampling run.
+struct UpdateDyn {
+  const float* noise;    // [t_start+1, M, F] or null
+  float* hist;           // [t_start+1, M, F] or null
+  unsigned long long seed;
+  long long seq_offset;
+  int t_start;
+  int pad_;
+};
+struct UpdateArgs {
+  const UpdateDyn* dyn;  // device pointer; when non-null it overrides noise/hist/seed/seq_offset/t_start
+  const float* g;        // [M, d]
+  const float* gamma;    // [d] or null
+  const float* beta;     // [d] or null
+  const float* w2;       // [F, d]
+  const float* b2;       // [F]
+  const float* x;        // [M, F]
+  const float* coef;     // [4, T]
+  const float* noise;    // [T, M, F] or null
+  long long noise_stride;  // elements between consecutive t rows of `noise` (0: a single [M,F] slab)
+  const int* t_dev;      // current step index
+  float* eps_out;        // [M, F] or null
+  float* x_out;          // [M, F] or null (null => forward only)
+  float* hist;           // [(t_start+1), M, F] or null
+  unsigned long long seed;
+  long long seq_offset;  // global index of sequence 0 (Philox key)
+  int t_start;
+  int T;
+  int M, L, F, d;
+  int do_ln;
+  float ln_eps;
+  unsigned angle_mask;   // bit f set => wrap feature f
+};
+void launch_head_update(const UpdateArgs& a, hipStream_t s);
+
+// *t_dev -= 1  (last node of the per-step graph)
+void launch_step_advance(int* t_dev, hipStream_t s);
+
+// out[i] = Philox normal for (seed, t, element i of [B][L][F] with seq_offset)
+void launch_philox_fill(float* out, unsigned long long seed, int t, long long seq_offset, int B, int L, int F,
+                        hipStream_t s);
+
+}  // namespace fdmi

@@ -1,0 +1,121 @@
+"""
+The two data-free dataset shells the sampler needs (host-side glue).
+
+``sampling.sample`` only reads ``sample_noise``, ``timesteps``,
+``alpha_beta_terms["betas"]``, ``feature_is_angular``, ``pad`` and, optionally,
+``dset.get_masked_means()`` from its ``train_dset`` argument
+(foldingdiff/sampling.py:150-156, :208-216).  These classes carry exactly that,
+with the reference's names and constructor arguments
+(foldingdiff/datasets.py:569-623 AnglesEmptyDataset, :685-799 NoisedAnglesDataset).
+The reference's own dataset objects can be passed to ``foldingdiff_amd.sampling``
+instead -- only the attributes above are used.
+"""
+import json
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import beta_schedules, utils
+
+FEATURE_SET_NAMES_TO_ANGULARITY = {
+    "canonical": [False, False, False, True, True, True, True, True, True],
+    "canonical-full-angles": [True, True, True, True, True, True],
+    "canonical-minimal-angles": [True, True, True, True],
+    "cart-coords": [False, False, False],
+}
+FEATURE_SET_NAMES_TO_FEATURE_NAMES = {
+    "canonical": ["0C:1N", "N:CA", "CA:C", "phi", "psi", "omega", "tau", "CA:C:1N", "C:1N:1CA"],
+    "canonical-full-angles": ["phi", "psi", "omega", "tau", "CA:C:1N", "C:1N:1CA"],
+    "canonical-minimal-angles": ["phi", "psi", "omega", "tau"],
+    "cart-coords": ["x", "y", "z"],
+}
+
+
+class AnglesEmptyDataset:
+    """Feature-set metadata + pad length + optional training mean offset; no data."""
+
+    def __init__(self, feature_set_key: str, pad: int = 128, mean_offset: Optional[np.ndarray] = None):
+        key = "coords" if feature_set_key == "cart-coords" else "angles"
+        self.feature_is_angular = {key: list(FEATURE_SET_NAMES_TO_ANGULARITY[feature_set_key])}
+        self.feature_names = {key: list(FEATURE_SET_NAMES_TO_FEATURE_NAMES[feature_set_key])}
+        self.pad = pad
+        self._mean_offset = mean_offset
+        if mean_offset is not None:
+            assert mean_offset.size == len(self.feature_names[key])
+
+    @classmethod
+    def from_dir(cls, dirname: str):
+        with open(os.path.join(dirname, "training_args.json")) as fh:
+            args = json.load(fh)
+        off_file = os.path.join(dirname, "training_mean_offset.npy")
+        offset = np.load(off_file) if os.path.isfile(off_file) else None
+        return cls(feature_set_key=args["angles_definitions"], pad=args["max_seq_len"], mean_offset=offset)
+
+    def get_masked_means(self) -> np.ndarray:
+        if self._mean_offset is None:
+            raise NotImplementedError
+        return np.copy(self._mean_offset)
+
+    def __len__(self):
+        raise NotImplementedError
+
+    def __getitem__(self, index):
+        raise NotImplementedError
+
+
+class NoisedAnglesDataset:
+    """Schedule + initial-noise carrier around a (possibly empty) dataset."""
+
+    def __init__(
+        self,
+        dset,
+        dset_key: str = "angles",
+        timesteps: int = 250,
+        exhaustive_t: bool = False,
+        beta_schedule: beta_schedules.SCHEDULES = "linear",
+        nonangular_variance: float = 1.0,
+        angular_variance: float = 1.0,
+    ) -> None:
+        assert hasattr(dset, "feature_names") and hasattr(dset, "feature_is_angular")
+        assert dset_key in dset.feature_is_angular, f"{dset_key} not in {dset.feature_is_angular}"
+        self.dset = dset
+        self.dset_key = dset_key
+        self.n_features = len(dset.feature_is_angular[dset_key])
+        self.nonangular_var_scale = nonangular_variance
+        self.angular_var_scale = angular_variance
+        self.timesteps = timesteps
+        self.schedule = beta_schedule
+        self.exhaustive_timesteps = exhaustive_t
+        self.alpha_beta_terms = beta_schedules.compute_alphas(
+            beta_schedules.get_variance_schedule(beta_schedule, timesteps)
+        )
+
+    @property
+    def feature_names(self):
+        return self.dset.feature_names
+
+    @property
+    def feature_is_angular(self):
+        return self.dset.feature_is_angular
+
+    @property
+    def pad(self):
+        return self.dset.pad
+
+    def sample_length(self, *args, **kwargs):
+        return self.dset.sample_length(*args, **kwargs)
+
+    def sample_noise(self, vals: torch.Tensor) -> torch.Tensor:
+        """N(0, 1) from the global CPU generator (same draw as the reference, so a
+        fixed ``torch.manual_seed`` gives the same start point), per-feature variance
+        scale, angular columns wrapped to [-pi, pi)."""
+        angular = self.dset.feature_is_angular[self.dset_key]
+        noise = torch.randn_like(vals)
+        if self.angular_var_scale != 1.0 or self.nonangular_var_scale != 1.0:
+            for j in range(noise.shape[-1]):
+                noise[..., j] *= self.angular_var_scale if angular[j] else self.nonangular_var_scale
+        idx = np.where(angular)[0]
+        noise[..., idx] = utils.modulo_with_wrapped_range(noise[..., idx], -np.pi, np.pi)
+        return noise

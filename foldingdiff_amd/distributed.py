@@ -1,0 +1,87 @@
+"""
+Multi-GPU sampling: independent sequences are sharded across the GPUs of one
+node, every rank runs the whole reverse process on its slice with NO per-step
+communication, and a single collective returns the final angles to rank 0
+(RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).
+
+The reference has no multi-GPU sampler (foldingdiff/sampling.py is single
+device, :91); this is the MI355X-native extension SURVEY 8(e) specifies.
+Sequences are independent (attention is within-sequence; the reference asserts
+batch-order equivariance in tests/test_transformer.py:136-162), weights are
+57.8 MB and simply replicated.
+
+Why one flat gather and not a ring: the payload is B/world x L x F fp32 per rank
+(1.57 MB at B/world = 512, L = 128) once per 1000 timesteps -- latency-bound on
+any xGMI topology; ``all_gather_into_tensor`` posts one RCCL collective.
+Philox noise is keyed by the GLOBAL sequence index (``seq_offset``), so the
+samples do not depend on the world size.
+"""
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) slice of ``n_items`` for ``rank`` (first
+    ``n_items % world`` ranks get one extra item)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_tokens(lengths: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Contiguous slices balanced by total tokens rather than by count (mixed-length
+    sweeps such as BASELINE config C3): cut r is placed at the prefix sum nearest to
+    r/world of the total.  Returns [lo, hi) per rank (possibly empty)."""
+    cum = [0]
+    for n in lengths:
+        cum.append(cum[-1] + int(n))
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        best = min(range(cuts[-1], len(cum)), key=lambda i: (abs(cum[i] - target), i))
+        cuts.append(best)
+    cuts.append(len(lengths))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def gather_final(local: torch.Tensor, counts: Sequence[int], group=None) -> Optional[torch.Tensor]:
+    """ONE collective: every rank contributes its [b_r, L, F] block; rank 0 gets the
+    concatenation in rank order ([sum b_r, L, F]), other ranks get None.  Ragged
+    ``counts`` are padded to the max so a single all_gather_into_tensor suffices."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(counts) == world and local.shape[0] == counts[rank]
+    bmax = max(counts)
+    pad = local
+    if local.shape[0] != bmax:
+        pad = torch.zeros((bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    out = torch.empty((world * bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if rank != 0:
+        return None
+    out = out.view((world, bmax) + tuple(local.shape[1:]))
+    return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+
+
+def sample_sharded(
+    run_local: Callable[[int, int], torch.Tensor],
+    n_items: int,
+    group=None,
+) -> Optional[torch.Tensor]:
+    """Shard ``n_items`` sequences over the ranks, call ``run_local(lo, hi)`` (which
+    must return the final [hi-lo, L, F] tensor for global sequences lo..hi-1, e.g. via
+    ``sampling.sample_on_device(..., seq_offset=lo)``), then gather once to rank 0."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_items, world, r)
+        counts.append(hi - lo)
+    lo, hi = shard_bounds(n_items, world, rank)
+    local = run_local(lo, hi)
+    assert local.shape[0] == hi - lo
+    return gather_final(local, counts, group=group)

@@ -1,0 +1,225 @@
+"""
+Sampling from the diffusion model on MI355X -- same entry points as
+foldingdiff/sampling.py (``p_sample`` :27-75, ``p_sample_loop`` :78-132,
+``sample`` :135-224, ``sample_simple`` :227-264), same arguments, same return
+types.  The 1000-step loop itself is one C-ABI call (``fd_sample`` /
+``fd_sample_dev``): a hipGraph of hand-written kernels replayed per timestep
+with the schedule tables and the step counter resident on the device.
+
+Per-step noise (the reference's ``torch.randn_like(x)``, sampling.py:73):
+  * ``NOISE_MODE = "torch"`` (default): the draws are taken from torch's global
+    CPU generator in the reference's order and uploaded, so after
+    ``torch.manual_seed(s)`` the sampled angles match the reference CPU path.
+  * ``NOISE_MODE = "philox"`` (or env ``FOLDINGDIFF_AMD_NOISE=philox``): noise is
+    generated inside the update kernel (Philox4x32-10); a 64-bit seed is drawn
+    from torch's CPU generator, so ``torch.manual_seed`` still makes runs
+    reproducible, but the stream is not torch's.
+"""
+import ctypes as C
+import json
+import logging
+import os
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _binding, beta_schedules, utils
+from . import datasets as dsets
+from . import modelling
+
+NOISE_MODE = os.environ.get("FOLDINGDIFF_AMD_NOISE", "torch")
+
+
+def _as_f32(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32, copy=False))
+
+
+def _lens_array(seq_lens: Sequence[int], B: int, L: int) -> np.ndarray:
+    lens = np.ascontiguousarray(np.asarray(list(seq_lens), dtype=np.int32))
+    assert lens.shape == (B,), f"need one length per batch item, got {lens.shape} for batch {B}"
+    if lens.min() < 1 or lens.max() > L:
+        raise ValueError(f"sequence lengths must lie in [1, {L}], got [{lens.min()}, {lens.max()}]")
+    return lens
+
+
+@torch.no_grad()
+def p_sample(model, x: torch.Tensor, t: torch.Tensor, seq_lens: Sequence[int], t_index, betas: torch.Tensor) -> torch.Tensor:
+    """One ancestral step x_t -> x_{t-1} WITHOUT the angular wrap (p_sample_loop wraps).
+    As in the reference, ``t`` must be constant over the batch and ``t_index`` is
+    ignored in favour of it (sampling.py:46-48)."""
+    t_unique = torch.unique(t)
+    assert len(t_unique) == 1, f"Got multiple values for t: {t_unique}"
+    ti = int(t_unique.item())
+    h = model.prepare(betas)
+    xs = _as_f32(x)
+    B, L, F = xs.shape
+    lens = _lens_array(seq_lens, B, L)
+    z = _as_f32(torch.randn_like(x)) if ti > 0 else None
+    out = np.empty_like(xs)
+    _binding.check(_binding.load().fd_p_sample_step(
+        h, xs.ctypes.data_as(C.c_void_p), ti, lens.ctypes.data_as(C.c_void_p), B, L,
+        z.ctypes.data_as(C.c_void_p) if z is not None else None, 0, out.ctypes.data_as(C.c_void_p)))
+    return torch.from_numpy(out).to(x.device)
+
+
+def _draw_step_noise(T: int, shape) -> np.ndarray:
+    """The reference's per-step draws as one [T, B, L, F] array: row i is the
+    ``torch.randn_like(x)`` taken at t_index i; drawn for i = T-1 ... 1 in that order,
+    one call per step (a single big randn call is NOT the same stream)."""
+    noise = np.zeros((T,) + tuple(shape), dtype=np.float32)
+    for i in reversed(range(1, T)):
+        noise[i] = torch.randn(tuple(shape), dtype=torch.float32).numpy()
+    return noise
+
+
+@torch.no_grad()
+def p_sample_loop(
+    model,
+    lengths: Sequence[int],
+    noise: torch.Tensor,
+    timesteps: int,
+    betas: torch.Tensor,
+    is_angle: Union[bool, List[bool]] = [False, True, True, True],
+    disable_pbar: bool = False,
+    final_only: bool = False,
+) -> torch.Tensor:
+    """Run the whole reverse process from ``noise``.  Returns a CPU tensor of shape
+    (timesteps, batch_size, seq_len, n_ft) -- entry j is the state after step
+    t = timesteps-1-j, last entry = the sample -- or (1, batch, seq_len, n_ft) holding
+    only the final sample when ``final_only`` (extension; skips the history copy)."""
+    assert len(betas) == timesteps, f"{len(betas)} betas for {timesteps} timesteps"
+    if not isinstance(is_angle, bool):
+        assert len(is_angle) == noise.shape[-1]
+    h = model.prepare(betas, is_angle)
+    x0 = _as_f32(noise)
+    B, L, F = x0.shape
+    lens = _lens_array(lengths, B, L)
+    logging.info(f"Starting from noise {tuple(noise.shape)} with angularity {is_angle} using {model.device}")
+    lib = _binding.load()
+    if NOISE_MODE == "torch":
+        zs = _draw_step_noise(timesteps, (B, L, F))
+        zptr, seed = zs.ctypes.data_as(C.c_void_p), 0
+    elif NOISE_MODE == "philox":
+        zs, zptr = None, None
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    else:
+        raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
+    out = np.empty(((1 if final_only else timesteps), B, L, F), dtype=np.float32)
+    _binding.check(lib.fd_sample(h, x0.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, L,
+                                 timesteps - 1, zptr, C.c_uint64(seed), out.ctypes.data_as(C.c_void_p),
+                                 0 if final_only else 1))
+    return torch.from_numpy(out)
+
+
+@torch.no_grad()
+def sample_on_device(
+    model,
+    x_init: torch.Tensor,
+    lens: torch.Tensor,
+    betas: torch.Tensor,
+    is_angle=None,
+    seed: int = 0,
+    seq_offset: int = 0,
+    noise: Optional[torch.Tensor] = None,
+    full_history: bool = False,
+    t_start: Optional[int] = None,
+) -> torch.Tensor:
+    """Device-resident variant: ``x_init`` [B, L, F] float32 and ``lens`` [B] int32 are
+    CUDA tensors, the result is a CUDA tensor ([B, L, F], or [t_start+1, B, L, F] with
+    ``full_history``).  Asynchronous on torch's current stream; nothing touches the host."""
+    assert x_init.is_cuda and lens.is_cuda and x_init.dtype == torch.float32 and lens.dtype == torch.int32
+    x_init, lens = x_init.contiguous(), lens.contiguous()
+    h = model.prepare(betas, is_angle)
+    B, L, F = x_init.shape
+    T = len(betas)
+    t_start = T - 1 if t_start is None else t_start
+    shape = (t_start + 1, B, L, F) if full_history else (B, L, F)
+    out = torch.empty(shape, dtype=torch.float32, device=x_init.device)
+    nptr = None
+    if noise is not None:
+        assert noise.is_cuda and noise.dtype == torch.float32 and tuple(noise.shape) == (t_start + 1, B, L, F)
+        noise = noise.contiguous()
+        nptr = C.c_void_p(noise.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(x_init.device).cuda_stream)
+    _binding.check(_binding.load().fd_sample_dev(
+        h, C.c_void_p(x_init.data_ptr()), C.c_void_p(lens.data_ptr()), B, L, t_start, nptr, C.c_uint64(seed),
+        C.c_int64(seq_offset), C.c_void_p(out.data_ptr()), 1 if full_history else 0, stream))
+    return out
+
+
+def sample(
+    model,
+    train_dset,
+    n: int = 10,
+    sweep_lengths: Optional[Tuple[int, int]] = (50, 128),
+    batch_size: int = 512,
+    feature_key: str = "angles",
+    disable_pbar: bool = False,
+    trim_to_length: bool = True,
+    final_only: bool = False,
+) -> List[np.ndarray]:
+    """Sample ``n`` backbones per length in ``range(*sweep_lengths)`` (upper bound
+    exclusive) -- or ``n`` backbones with lengths from ``train_dset.sample_length()``
+    when ``sweep_lengths`` is None.  Returns one array per backbone of shape
+    (timesteps, seq_len, fts); index -1 is the sample.  ``final_only=True`` (extension)
+    returns arrays of shape (1, seq_len, fts) and never materialises the history.
+
+    ``train_dset`` needs ``sample_noise``, ``timesteps``, ``alpha_beta_terms``,
+    ``feature_is_angular``, ``pad`` (and optionally ``sample_length``,
+    ``dset.get_masked_means``), as the reference documents."""
+    if sweep_lengths is not None:
+        lo, hi = sweep_lengths
+        if not lo < hi:
+            raise ValueError(f"Minimum length {lo} must be less than maximum {hi}")
+        logging.info(f"Sweeping from {lo}-{hi} with {n} examples at each length")
+        lengths = [l for l in range(lo, hi) for _ in range(n)]
+    else:
+        lengths = [train_dset.sample_length() for _ in range(n)]
+    logging.info(f"Sampling {len(lengths)} items in batches of size {batch_size}")
+    results: List[np.ndarray] = []
+    for start in range(0, len(lengths), batch_size):
+        these = lengths[start : start + batch_size]
+        noise = train_dset.sample_noise(torch.zeros((len(these), train_dset.pad, model.n_inputs), dtype=torch.float32))
+        if trim_to_length:
+            noise = noise[:, : max(these), :]
+        traj = p_sample_loop(
+            model=model, lengths=these, noise=noise, timesteps=train_dset.timesteps,
+            betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
+            disable_pbar=disable_pbar, final_only=final_only)
+        results.extend(traj[:, i, :l, :].numpy() for i, l in enumerate(these))
+    inner = getattr(train_dset, "dset", None)
+    offset = None
+    if inner is not None and hasattr(inner, "get_masked_means"):
+        try:
+            offset = inner.get_masked_means()
+        except NotImplementedError:
+            # AnglesEmptyDataset without training_mean_offset.npy: the reference would
+            # raise here (datasets.py:613-617); treat "no offset" as "no shift".
+            offset = None
+    if offset is not None:
+        logging.info(f"Shifting predicted values by original offset: {offset}")
+        results = [s + offset for s in results]
+        angular_idx = np.where(train_dset.feature_is_angular[feature_key])[0]
+        for s in results:
+            s[..., angular_idx] = utils.modulo_with_wrapped_range(s[..., angular_idx], range_min=-np.pi, range_max=np.pi)
+    return results
+
+
+def sample_simple(model_dir: str, n: int = 10, sweep_lengths: Tuple[int, int] = (50, 128)):
+    """Load model + dummy dataset from ``model_dir`` and return one DataFrame of final
+    angles per sampled backbone."""
+    import pandas as pd
+
+    assert os.path.isdir(model_dir), f"{model_dir} is not a local model directory (no network here)"
+    with open(os.path.join(model_dir, "training_args.json")) as fh:
+        targs = json.load(fh)
+    model = modelling.BertForDiffusionBase.from_dir(model_dir).to("cuda:0")
+    dummy = dsets.AnglesEmptyDataset.from_dir(model_dir)
+    noised = dsets.NoisedAnglesDataset(
+        dset=dummy, dset_key="coords" if targs.get("angles_definitions") == "cart-coords" else "angles",
+        timesteps=targs["timesteps"], exhaustive_t=False, beta_schedule=targs["variance_schedule"],
+        nonangular_variance=1.0, angular_variance=targs["variance_scale"])
+    sampled = sample(model, noised, n=n, sweep_lengths=sweep_lengths, disable_pbar=True)
+    key = noised.dset_key
+    return [pd.DataFrame(s[-1], columns=noised.feature_names[key]) for s in sampled]

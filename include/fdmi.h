@@ -1,0 +1,174 @@
+/*
+ * fdmi.h -- C ABI of libfdmi.so, the MI355X (gfx950) reverse-diffusion sampler
+ * for foldingdiff's BertForDiffusion backbone-angle model.
+ *
+ * The reference (microsoft/foldingdiff) is 100% Python and has NO FFI / plugin
+ * interface of its own; its boundary for this path is the Python API
+ *     modelling.BertForDiffusionBase.from_dir / .forward   (foldingdiff/modelling.py:297-484)
+ *     sampling.p_sample / p_sample_loop / sample           (foldingdiff/sampling.py:27-224)
+ * Each entry point below names the reference function it replaces.  The Python
+ * package `foldingdiff_amd` binds these with ctypes and re-exposes the
+ * reference's names and signatures.
+ *
+ * Conventions
+ *  - plain C types only; no torch / HIP types in signatures (streams and device
+ *    buffers cross as void*).
+ *  - every function returns FD_OK (0) or a negative FD_E_* code; the message is
+ *    available from fd_last_error() (thread local).  Nothing throws across the ABI.
+ *  - "host" pointers are ordinary host memory, copied synchronously.  "dev"
+ *    pointers are device memory on the model's device (hipMalloc / torch CUDA
+ *    tensors), used in place on the given stream.
+ *  - one fd_model per device; calls on one model are serialised by the caller.
+ *  - all tensors are contiguous row-major float32 unless stated otherwise:
+ *    angles x[B][L][F], lengths int32[B], history [T][B][L][F].
+ */
+#ifndef FDMI_H
+#define FDMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDMI_ABI_VERSION 1
+
+enum {
+  FD_OK = 0,
+  FD_E_INVALID = -1,     /* bad argument / unsupported shape            */
+  FD_E_STATE = -2,       /* call order (e.g. sample before finalize)    */
+  FD_E_MISSING = -3,     /* a required weight was never set             */
+  FD_E_HIP = -4,         /* HIP runtime error (message has hipGetErrorString) */
+  FD_E_UNSUPPORTED = -5  /* valid in the reference, not implemented here */
+};
+
+/* config.position_embedding_type (config.json; modelling.py:138-149, HF BertSelfAttention) */
+enum { FD_POS_ABSOLUTE = 0, FD_POS_RELATIVE_KEY = 1, FD_POS_RELATIVE_KEY_QUERY = 2 };
+/* training_args.json "decoder" (modelling.py:274-279) */
+enum { FD_DEC_MLP = 0, FD_DEC_LINEAR = 1 };
+/* arithmetic of the contraction kernels */
+enum {
+  FD_PREC_F32 = 0 /* v_mfma_f32_32x32x2_f32: exact fp32 products + fp32 accumulate (parity path) */
+};
+
+typedef struct fd_model fd_model;
+
+/* Shapes of BertConfig + training_args.json that the hot path reads
+ * (bin/train.py:425-435; modelling.py:239-295). */
+typedef struct fd_config {
+  int32_t n_features; /* F  = len(ft_is_angular)  (modelling.py:255-256) */
+  int32_t d_model;    /* config.hidden_size */
+  int32_t n_heads;    /* config.num_attention_heads; head size must be 32 */
+  int32_t d_ff;       /* config.intermediate_size */
+  int32_t n_layers;   /* config.num_hidden_layers */
+  int32_t max_pos;    /* config.max_position_embeddings */
+  int32_t pos_type;   /* FD_POS_* */
+  int32_t decoder;    /* FD_DEC_* */
+  float ln_eps;       /* config.layer_norm_eps (embeddings + encoder LayerNorms);
+                         the decoder head LayerNorm always uses 1e-12 (modelling.py:187) */
+} fd_config;
+
+/* ---- construction: replaces BertForDiffusionBase.__init__/from_dir (modelling.py:239-382) ---- */
+
+int fd_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int fd_device_count(void);
+
+/* Create an empty model on HIP device `device_id`. */
+int fd_create(const fd_config* cfg, int device_id, fd_model** out);
+
+/* Provide one tensor of the reference state_dict, by its HuggingFace /
+ * modelling.py name (e.g. "encoder.layer.3.attention.self.query.weight",
+ * "token_decoder.dense2.bias"; full list in DESIGN.md).  Replaces
+ * load_state_dict (modelling.py:362-363).  Shape is checked against cfg.
+ * Non-parameter buffers ("time_embed.W", "embeddings.position_ids") are accepted
+ * and ignored: the time embedding reaches the device as a table (fd_finalize). */
+int fd_set_weight(fd_model* m, const char* name, const float* host_data, const int64_t* shape, int ndim);
+
+/* Pack weights, upload the schedule + time-embedding tables, build kernels' state.
+ *   T           number of diffusion timesteps (NoisedAnglesDataset.timesteps)
+ *   coef        float[4][T] rows: sqrt(1/alpha_t), beta_t, sqrt(1-alphabar_t),
+ *               sqrt(posterior_variance_t)  -- from compute_alphas
+ *               (beta_schedules.py:45-62) as used by p_sample (sampling.py:41-72)
+ *   time_table  float[T][d_model]: time_embed(t) for t = 0..T-1, computed on the
+ *               host with the reference's fp32 op order (modelling.py:59-71)
+ *   is_angle    uint8[F]: which features are wrapped to [-pi, pi) each step
+ *               (sampling.py:119-130)
+ *   precision   FD_PREC_*
+ * May be called again to change T / tables. */
+int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, const uint8_t* is_angle,
+                int precision);
+
+void fd_destroy(fd_model* m);
+
+/* Runtime switches (all default on):
+ *   "fuse_ln"    1: residual + LayerNorm run in the epilogue of the attention-output and
+ *                FFN-down GEMMs; 0: separate LayerNorm kernel (same arithmetic).
+ *   "use_graph"  1: the per-step kernel sequence is replayed from a hipGraph; 0: eager launches. */
+int fd_set_option(fd_model* m, const char* name, int value);
+
+/* ---- parity hooks ---- */
+
+/* eps = model(x, t, attention_mask(lens)) -- BertForDiffusionBase.forward in eval
+ * mode (modelling.py:384-484).  Host buffers.  t is constant over the batch, as
+ * p_sample asserts (sampling.py:46-47). */
+int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, float* eps_out);
+
+/* One reverse step: x_out = p_sample(x, t) (sampling.py:27-75); with wrap != 0 the
+ * loop's per-feature wrap to [-pi, pi) (sampling.py:119-130) is applied as well, i.e.
+ * the result is one iteration of p_sample_loop.  z is the N(0,1) draw the reference
+ * takes from torch.randn_like (required for t > 0, ignored at t == 0).  Host buffers. */
+int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, const float* z,
+                     int wrap, float* x_out);
+
+/* ---- the sampler: replaces p_sample_loop (sampling.py:78-132) ----
+ *   x_init   [B][L][F] start point (already wrapped noise, datasets.py:772-799)
+ *   lens     int32[B], 1 <= lens[i] <= L; positions >= lens[i] are masked keys
+ *   t_start  first timestep index to run (T-1 for a full run); the loop runs
+ *            t = t_start, t_start-1, ..., 0  (t_start+1 steps)
+ *   noise    [t_start+1][B][L][F] per-step N(0,1) draws, row i used at t = i
+ *            (row 0 unused), or NULL => on-device Philox4x32-10 keyed by
+ *            (seed, t, element) -- deterministic, but NOT torch's stream
+ *   out      full_history ? [t_start+1][B][L][F] (row j = state after step
+ *            t = t_start - j, i.e. the reference's stacked `imgs`) : [B][L][F]
+ * The per-step loop is a captured hipGraph replayed t_start+1 times; the step
+ * index lives on the device. */
+int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
+              uint64_t seed, float* out, int full_history);
+
+/* Same, with every buffer already resident in device memory, asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = the model's own stream).  The caller
+ * synchronises.  `seq_offset` is added to the sequence index in the Philox key
+ * so a batch sharded over several GPUs draws the noise of the unsharded batch. */
+int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
+                  const void* noise_dev, uint64_t seed, int64_t seq_offset, void* out_dev, int full_history,
+                  void* hip_stream);
+
+/* Fill out_dev[n] (device, float32) with the Philox N(0,1) stream used for step
+ * t of a [B][L][F] batch -- exposes the perf-mode generator for tests. */
+int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, int B, int L, void* out_dev,
+                         void* hip_stream);
+
+/* ---- measurement ---- */
+
+/* When n > 0, every n-th reverse step of fd_sample* is launched eagerly with a
+ * hipEvent pair around each kernel instead of replaying the graph, and the
+ * durations are accumulated per kernel class.  0 disables (default). */
+int fd_profile_every(fd_model* m, int n);
+int fd_profile_reset(fd_model* m);
+/* Number of kernel classes; name / accumulated ms / launch count / algorithmic
+ * FLOPs and HBM bytes per launch for class i at the last profiled shape. */
+int fd_profile_count(fd_model* m);
+int fd_profile_get(fd_model* m, int i, const char** name, double* total_ms, int64_t* launches,
+                   double* flops_per_launch, double* bytes_per_launch);
+
+/* Block until all work queued on the model's own stream is done. */
+int fd_synchronize(fd_model* m);
+
+const char* fd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDMI_H */

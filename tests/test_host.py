@@ -1,0 +1,160 @@
+"""
+Host-side logic of the product package (no GPU): tables, wrap, dataset shells,
+model construction / from_dir / state_dict plumbing, argument validation.  The
+product's host tables must be bit-identical to the reference's (golden fixtures).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from foldingdiff_amd import beta_schedules, datasets, modelling, sampling, utils
+
+
+def test_schedules_match_reference_bitwise():
+    g = golden("ref_schedules.npz")
+    for kind in ("cosine", "linear", "quadratic"):
+        for T in (10, 250, 1000):
+            terms = beta_schedules.compute_alphas(beta_schedules.get_variance_schedule(kind, T))
+            for k, v in terms.items():
+                assert np.array_equal(v.numpy(), g[f"{kind}_{T}_{k}"]), (kind, T, k)
+    with pytest.raises(ValueError):
+        beta_schedules.get_variance_schedule("nope", 10)
+
+
+def test_step_coefficients():
+    g = golden("ref_schedules.npz")
+    c = beta_schedules.step_coefficients(beta_schedules.cosine_beta_schedule(1000)).numpy()
+    assert c.shape == (4, 1000) and c.dtype == np.float32
+    assert np.array_equal(c[0], (1.0 / torch.sqrt(torch.from_numpy(g["cosine_1000_alphas"]))).numpy())
+    assert np.array_equal(c[1], g["cosine_1000_betas"])
+    assert np.array_equal(c[2], g["cosine_1000_sqrt_one_minus_alphas_cumprod"])
+    # torch.sqrt (what p_sample calls, sampling.py:75) is not numpy's correctly-rounded sqrt on every input
+    assert np.array_equal(c[3], torch.sqrt(torch.from_numpy(g["cosine_1000_posterior_variance"])).numpy())
+    assert c[3, 0] == 0.0  # t = 0 adds no noise
+
+
+def test_wrap_kats():
+    g = golden("ref_wrap.npz")
+    assert np.array_equal(utils.modulo_with_wrapped_range(torch.from_numpy(g["v"]), -np.pi, np.pi).numpy(), g["w"])
+    for (a, lo, hi), want in zip(g["kat_in"], g["kat_out"]):
+        assert utils.modulo_with_wrapped_range(a, lo, hi) == want
+    assert np.allclose(utils.modulo_with_wrapped_range(np.array([2, -2]), -2, 2), [-2, -2])
+    with pytest.raises(AssertionError):
+        utils.modulo_with_wrapped_range(1.0, 1.0, 2.0)
+
+
+def test_sample_noise_matches_reference():
+    g = golden("ref_noise.npz")
+    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=128),
+                                      timesteps=10, beta_schedule="cosine")
+    torch.manual_seed(7344)
+    assert np.array_equal(ds.sample_noise(torch.zeros(3, 128, 6)).numpy(), g["full_seed7344"])
+    ds2 = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical", pad=32), timesteps=10,
+                                       beta_schedule="linear", angular_variance=0.5)
+    torch.manual_seed(99)
+    assert np.array_equal(ds2.sample_noise(torch.zeros(2, 32, 9)).numpy(), g["mixed_seed99_var05"])
+    assert ds.pad == 128 and ds.timesteps == 10 and ds.feature_is_angular["angles"] == [True] * 6
+    with pytest.raises(NotImplementedError):
+        ds.dset.get_masked_means()
+
+
+def test_time_tables_match_reference():
+    g = golden("ref_time_embed.npz")
+    assert np.array_equal(modelling.gaussian_fourier_table(torch.from_numpy(g["W"]), 1000).numpy(), g["gaussian_fourier"])
+    assert np.array_equal(modelling.sinusoidal_table(64, 1000).numpy(), g["sinusoidal"])
+
+
+def _mini_cfg(**kw):
+    base = dict(hidden_size=64, num_attention_heads=2, intermediate_size=128, num_hidden_layers=2,
+                max_position_embeddings=64, position_embedding_type="relative_key")
+    base.update(kw)
+    return modelling.BertConfig(**base)
+
+
+def test_model_state_dict_names_match_oracle():
+    from oracle import ref_model
+    for pos in ("relative_key", "absolute"):
+        for dec in ("mlp", "linear"):
+            m = modelling.BertForDiffusionBase(_mini_cfg(position_embedding_type=pos), [True] * 6, decoder=dec)
+            o = ref_model.OracleBertForDiffusion(
+                ref_model.OracleConfig(hidden_size=64, num_attention_heads=2, intermediate_size=128,
+                                       num_hidden_layers=2, max_position_embeddings=64, position_embedding_type=pos),
+                [True] * 6, decoder=dec)
+            assert set(m.state_dict().keys()) == set(o.state_dict().keys())
+            for k, v in o.state_dict().items():
+                assert tuple(m.state_dict()[k].shape) == tuple(v.shape), k
+            m.load_state_dict(o.state_dict())  # strict
+            with pytest.raises(RuntimeError):
+                bad = dict(o.state_dict())
+                bad.pop("inputs_to_hidden_dim.bias")
+                m.load_state_dict(bad)
+
+
+def test_from_dir_roundtrip(tmp_path):
+    """Reference directory layout: training_args.json, config.json,
+    models/best_by_valid/epoch=N-step=M.ckpt with a 'state_dict' key (modelling.py:297-382)."""
+    d = tmp_path / "results"
+    (d / "models" / "best_by_valid").mkdir(parents=True)
+    cfg = _mini_cfg()
+    cfg.save_pretrained(d)
+    with open(d / "training_args.json", "w") as fh:
+        json.dump({"angles_definitions": "canonical-full-angles", "time_encoding": "gaussian_fourier",
+                   "decoder": "mlp", "max_seq_len": 64, "timesteps": 10, "variance_schedule": "cosine",
+                   "variance_scale": 1.0}, fh)
+    src = modelling.BertForDiffusionBase(cfg, [True] * 6)
+    for epoch in (3, 12):  # latest epoch must win, idx=-1
+        sd = {k: v + epoch for k, v in src.state_dict().items()}
+        torch.save({"state_dict": sd, "epoch": epoch}, d / "models" / "best_by_valid" / f"epoch={epoch}-step={epoch * 10}.ckpt")
+    m = modelling.BertForDiffusionBase.from_dir(str(d), copy_to=str(tmp_path / "snap"))
+    assert m.n_inputs == 6 and m.ft_is_angular == [True] * 6
+    assert torch.equal(m.state_dict()["inputs_to_hidden_dim.bias"], src.state_dict()["inputs_to_hidden_dim.bias"] + 12)
+    assert os.path.isfile(tmp_path / "snap" / "models" / "best_by_valid" / "epoch=12-step=120.ckpt")
+    assert os.path.isfile(tmp_path / "snap" / "config.json") and os.path.isfile(tmp_path / "snap" / "training_args.json")
+    m0 = modelling.BertForDiffusionBase.from_dir(str(d), idx=0)
+    assert torch.equal(m0.state_dict()["inputs_to_hidden_dim.bias"], src.state_dict()["inputs_to_hidden_dim.bias"] + 3)
+    m2 = modelling.BertForDiffusionBase.from_dir(str(tmp_path / "snap"))
+    assert torch.equal(m2.state_dict()["time_embed.W"], m.state_dict()["time_embed.W"])
+    ds = datasets.AnglesEmptyDataset.from_dir(str(d))
+    assert ds.pad == 64
+
+
+def test_no_cpu_compute_path():
+    m = modelling.BertForDiffusionBase(_mini_cfg(), [True] * 6)
+    assert next(m.parameters()).device.type == "cpu"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 8, 6), torch.zeros(1, dtype=torch.long), attention_mask=torch.ones(1, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sampling.p_sample_loop(m, [8], torch.zeros(1, 8, 6), 10, beta_schedules.cosine_beta_schedule(10), [True] * 6)
+
+
+def test_argument_validation():
+    m = modelling.BertForDiffusionBase(_mini_cfg(), [True] * 6)
+    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=64), timesteps=10,
+                                      beta_schedule="cosine")
+    with pytest.raises(ValueError, match="must be less than"):
+        sampling.sample(m, ds, n=1, sweep_lengths=(50, 50))
+    with pytest.raises(NotImplementedError):
+        modelling.BertForDiffusionBase.lengths_from_mask(torch.tensor([[1.0, 0.0, 1.0]]))
+    assert modelling.BertForDiffusionBase.lengths_from_mask(torch.tensor([[1.0, 1.0, 0.0], [1, 1, 1]])).tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        modelling.BertForDiffusionBase(_mini_cfg(), [True] * 6, decoder="cnn")
+    with pytest.raises(ValueError):
+        modelling.BertForDiffusionBase(_mini_cfg(), [True] * 6, time_encoding="learned")
+    with pytest.raises(AssertionError):
+        sampling.p_sample(m, torch.zeros(2, 8, 6), torch.tensor([1, 2]), [8, 8], 0, beta_schedules.cosine_beta_schedule(10))
+    assert not utils.is_huggingface_hub_id(os.getcwd())
+    assert utils.is_huggingface_hub_id("wukevin/foldingdiff_cath")
+
+
+def test_step_noise_draw_order_matches_reference():
+    """_draw_step_noise must replicate the reference's sequence of randn_like draws
+    (golden: recovered from the reference run in make_golden.py)."""
+    g = golden("ref_abs_traj.npz")
+    torch.manual_seed(2024)
+    _ = torch.randn(4, 128, 6)  # the initial sample_noise draw
+    z = sampling._draw_step_noise(int(g["T"]), (4, 48, 6))
+    assert np.array_equal(z, g["step_noise"])
