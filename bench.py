@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the reverse-diffusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): backbones/sec at L=128, T=1000, batch 512 per GPU
+(config C2; C4 = the same per-GPU batch on 8 GPUs, i.e. weak scaling).
+
+A "step" = ONE PASS of the hot path over one batch: the whole T=1000 reverse
+process for 512 length-128 backbones per GPU (1000 replays of the per-timestep
+hipGraph), state + history resident in HBM, Philox noise generated in the update
+kernel, then (N > 1) the single RCCL gather of the final angles to rank 0.
+Inputs (x_T, lengths, weights, tables) are resident in HBM before the timed
+region starts.  Nothing is skipped or cached between passes.
+
+The JSON line also carries
+  roofline      the dominant kernel (QKV-projection GEMM): algorithmic FLOPs per launch /
+                average launch duration measured live with hipEvents inside the timed
+                region (every 100th timestep is launched eagerly with an event pair per
+                kernel instead of replaying the graph), against the dense fp32-MFMA peak.
+  cpu_baseline  the reference CPU path (oracle restatement, "port") timed on this box's
+                host cores over a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+RELEASED = dict(hidden_size=384, num_attention_heads=12, intermediate_size=768, num_hidden_layers=12,
+                max_position_embeddings=128, position_embedding_type="relative_key")  # config_jsons/cath_full_angles_cosine.json
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_token(L, d=384, ff=768, layers=12, F=6):
+    # N_layers*(8d^2 + 4*d*d_ff + 6*L*d) + 2*F*d + 2*d^2 + 2*d*F
+    return layers * (8 * d * d + 4 * d * ff + 6 * L * d) + 2 * F * d + 2 * d * d + 2 * d * F
+
+
+def cpu_baseline(L, T, budget_s=15.0):
+    """Reference CPU path (oracle port of foldingdiff/sampling.py p_sample_loop + the restated
+    BertForDiffusion), all host cores, on a bounded sample: a few consecutive reverse steps at a
+    reduced batch, extrapolated to T steps (steps are homogeneous)."""
+    from oracle import ref_model, ref_sampling
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    model = ref_model.synthetic_model(ref_model.OracleConfig(**RELEASED), seed=0, perturb=False)
+    Bc = 32
+    betas = ref_sampling.beta_schedule("cosine", T)
+    torch.manual_seed(0)
+    x = ref_sampling.initial_noise((Bc, L, 6), [True] * 6)
+    lens = [L] * Bc
+
+    def run(nsteps):
+        img = x.clone()
+        t0 = time.perf_counter()
+        for i in reversed(range(T - nsteps, T)):
+            img = ref_sampling.p_sample(model, img, torch.full((Bc,), i, dtype=torch.long), lens, betas)
+            img = ref_sampling.wrap(img, -torch.pi, torch.pi)
+        return time.perf_counter() - t0
+
+    run(1)  # warm-up (thread pools, MKL)
+    per_step = run(1)
+    n = max(2, min(40, int(budget_s / max(per_step, 1e-3))))
+    per_step = run(n) / n
+    return {
+        "value": Bc / (per_step * T),
+        "unit": "backbones/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} consecutive reverse steps at batch {Bc}, L={L} (of T={T}), torch fp32 eval-mode, "
+                  f"extrapolated x{T}/{n}; {per_step * 1e3:.1f} ms/step",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed passes (one pass = T reverse steps over the batch)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=512, help="sequences per GPU")
+    ap.add_argument("--length", type=int, default=128)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--profile-every", type=int, default=100)
+    ap.add_argument("--no-history", action="store_true", help="do not keep the [T,B,L,F] history in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-ln", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from foldingdiff_amd import _binding, beta_schedules, datasets, modelling, sampling
+    from foldingdiff_amd import distributed as fdist
+
+    B, L, T = args.batch, args.length, args.timesteps
+    torch.manual_seed(0)
+    model = modelling.BertForDiffusionBase(modelling.BertConfig(**RELEASED), [True] * 6).to(dev)  # HF init, seed 0
+    betas = beta_schedules.cosine_beta_schedule(T)
+    h = model.prepare(betas)
+    model.set_option("fuse_ln", args.fuse_ln)
+    lib = _binding.load()
+    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=128), timesteps=T,
+                                      beta_schedule="cosine")
+    torch.manual_seed(7344 + rank)  # bin/sample.py:34-37 default seed
+    x_init = ds.sample_noise(torch.zeros(B, 128, 6))[:, :L].contiguous().to(dev)
+    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    counts = [B] * world
+    seq_offset = rank * B
+    side = torch.cuda.Stream(device=dev)
+
+    def one_pass(seed):
+        with torch.cuda.stream(side):
+            out = sampling.sample_on_device(model, x_init, lens, betas, seed=seed, seq_offset=seq_offset,
+                                            full_history=not args.no_history)
+            final = out[-1] if not args.no_history else out
+            if world > 1:
+                return fdist.gather_final(final.contiguous(), counts)
+            return final
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    _binding.check(lib.fd_profile_every(h, 0))
+    for w in range(args.warmup):
+        one_pass(1000 + w)
+    sync_all()
+    _binding.check(lib.fd_profile_reset(h))
+    _binding.check(lib.fd_profile_every(h, args.profile_every))
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        last = one_pass(k)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _binding.check(lib.fd_profile_every(h, 0))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        assert last is not None and tuple(last.shape) == (B * world, L, 6)
+        assert torch.isfinite(last).all() and float(last.abs().max()) <= 3.1415927 + 1e-5
+
+    # per-kernel stats measured inside the timed region
+    kernels = {}
+    name_p, ms, n, fl, by = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    for i in range(lib.fd_profile_count(h)):
+        _binding.check(lib.fd_profile_get(h, i, C.byref(name_p), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        if n.value:
+            avg_ms = ms.value / n.value
+            kernels[name_p.value.decode()] = {
+                "avg_ms": avg_ms, "launches": n.value, "tflops": fl.value / (avg_ms * 1e-3) / 1e12,
+                "gbs": by.value / (avg_ms * 1e-3) / 1e9, "flops": fl.value, "bytes": by.value}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_backbones = B * world * args.steps
+    value = n_backbones / elapsed
+    flop_per_backbone = flops_per_token(L) * L * T
+    dom = kernels.get("gemm_qkv")
+    roofline = None
+    if dom:
+        roofline = {
+            "kernel": "gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384)",
+            "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "flops_per_launch": dom["flops"],
+        }
+    result = {
+        "metric": "backbones/sec (L=128, T=1000, bs=512)",
+        "value": value,
+        "unit": "backbones/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"C2: released foldingdiff_cath shape (d=384,H=12,d_ff=768,12 layers,relative_key), "
+                               f"L={L}, T={T}, batch {B}/GPU, synthetic HF-init weights, Philox noise, "
+                               f"history {'off' if args.no_history else 'in HBM'}",
+                   "global_batch": B * world, "seq_len": L, "timesteps": T, "parallelism": f"batch-shard x{world}",
+                   "fuse_ln": args.fuse_ln},
+        "whole_step": {"algorithmic_tflops": value * flop_per_backbone / 1e12 / world,
+                       "frac_of_f32_mfma_peak": value * flop_per_backbone / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+                       "ms_per_timestep": elapsed / args.steps / T * 1e3},
+        "roofline": roofline,
+        "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
+                        "launches": v["launches"]} for k, v in kernels.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(L, T)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

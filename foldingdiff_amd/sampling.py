@@ -124,10 +124,14 @@ def sample_on_device(
     noise: Optional[torch.Tensor] = None,
     full_history: bool = False,
     t_start: Optional[int] = None,
+    sync: bool = True,
 ) -> torch.Tensor:
     """Device-resident variant: ``x_init`` [B, L, F] float32 and ``lens`` [B] int32 are
     CUDA tensors, the result is a CUDA tensor ([B, L, F], or [t_start+1, B, L, F] with
-    ``full_history``).  Asynchronous on torch's current stream; nothing touches the host."""
+    ``full_history``); nothing touches the host.  Under a non-default torch stream the work is
+    enqueued on that stream (asynchronous, stream-ordered).  Under torch's default (null)
+    stream it runs on the model's own stream: pending torch work is waited for first and,
+    unless ``sync=False``, the call returns after the sampler finished."""
     assert x_init.is_cuda and lens.is_cuda and x_init.dtype == torch.float32 and lens.dtype == torch.int32
     x_init, lens = x_init.contiguous(), lens.contiguous()
     h = model.prepare(betas, is_angle)
@@ -141,10 +145,17 @@ def sample_on_device(
         assert noise.is_cuda and noise.dtype == torch.float32 and tuple(noise.shape) == (t_start + 1, B, L, F)
         noise = noise.contiguous()
         nptr = C.c_void_p(noise.data_ptr())
-    stream = C.c_void_p(torch.cuda.current_stream(x_init.device).cuda_stream)
-    _binding.check(_binding.load().fd_sample_dev(
+    ts = torch.cuda.current_stream(x_init.device)
+    own_stream = ts.cuda_stream == 0
+    if own_stream:
+        ts.synchronize()
+    lib = _binding.load()
+    _binding.check(lib.fd_sample_dev(
         h, C.c_void_p(x_init.data_ptr()), C.c_void_p(lens.data_ptr()), B, L, t_start, nptr, C.c_uint64(seed),
-        C.c_int64(seq_offset), C.c_void_p(out.data_ptr()), 1 if full_history else 0, stream))
+        C.c_int64(seq_offset), C.c_void_p(out.data_ptr()), 1 if full_history else 0,
+        None if own_stream else C.c_void_p(ts.cuda_stream)))
+    if own_stream and sync:
+        _binding.check(lib.fd_synchronize(h))
     return out
 
 
