@@ -98,7 +98,7 @@ struct fd_model {
   float *hd_w1 = nullptr, *hd_b1 = nullptr, *hd_g = nullptr, *hd_b = nullptr, *hd_w2 = nullptr, *hd_b2 = nullptr;
   float *coef = nullptr, *time_table = nullptr;
   // options
-  int fuse_ln = 1;
+  int fuse_ln = 0;  // measured: the LN-fused GEMM (1 wave/SIMD) is slower than GEMM + LayerNorm kernel
   int use_graph = 1;
   Workspace ws;
   // profiling

@@ -102,10 +102,11 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
 
 void fd_destroy(fd_model* m);
 
-/* Runtime switches (all default on):
+/* Runtime switches:
  *   "fuse_ln"    1: residual + LayerNorm run in the epilogue of the attention-output and
- *                FFN-down GEMMs; 0: separate LayerNorm kernel (same arithmetic).
- *   "use_graph"  1: the per-step kernel sequence is replayed from a hipGraph; 0: eager launches. */
+ *                FFN-down GEMMs; 0 (default): separate LayerNorm kernel (same arithmetic).
+ *   "use_graph"  1 (default): the per-step kernel sequence is replayed from a hipGraph;
+ *                0: eager launches. */
 int fd_set_option(fd_model* m, const char* name, int value);
 
 /* ---- parity hooks ---- */
