@@ -39,7 +39,15 @@ import torch  # noqa: E402
 RELEASED = dict(hidden_size=384, num_attention_heads=12, intermediate_size=768, num_hidden_layers=12,
                 max_position_embeddings=128, position_embedding_type="relative_key")  # config_jsons/cath_full_angles_cosine.json
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (2:1-sparsity figures are NOT used)
 PEAK_HBM_GBS = 8000.0
+PRECISION_INFO = {
+    "f32": dict(peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
+                kernel="gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384; v_mfma_f32_32x32x2_f32)"),
+    "f16x3": dict(peak=PEAK_F16_MFMA_TFLOPS, dtype="f32 (fp16 hi/lo split operands, 3x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
+                  kernel="gemm_f16x3_kernel<EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384; algorithmic FLOPs counted once, "
+                         "the 3 MFMAs per product are overhead against the dense fp16 peak)"),
+}
 
 
 def flops_per_token(L, d=384, ff=768, layers=12, F=6):
@@ -108,6 +116,7 @@ def main():
     ap.add_argument("--no-history", action="store_true", help="do not keep the [T,B,L,F] history in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-ln", type=int, default=0)
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM arithmetic (default: library default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,6 +142,8 @@ def main():
     torch.manual_seed(0)
     model = modelling.BertForDiffusionBase(modelling.BertConfig(**RELEASED), [True] * 6).to(dev)  # HF init, seed 0
     betas = beta_schedules.cosine_beta_schedule(T)
+    if args.precision:
+        model.set_precision(args.precision)
     h = model.prepare(betas)
     model.set_option("fuse_ln", args.fuse_ln)
     if os.environ.get("FDMI_NO_GRAPH") == "1":  # e.g. under rocprofv3 --pmc
@@ -203,13 +214,21 @@ def main():
     value = n_backbones / elapsed
     flop_per_backbone = flops_per_token(L) * L * T
     dom = kernels.get("gemm_qkv")
+    pinfo = PRECISION_INFO[model.precision]
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (separate runs, see profiles/)
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh).get(model.precision, {}).get("bytes")
+    except OSError:
+        pass
     roofline = None
     if dom:
         roofline = {
-            "kernel": "gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384)",
-            "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "kernel": pinfo["kernel"],
+            "bound": "mfma", "achieved": dom["tflops"], "peak": pinfo["peak"], "unit": "TFLOP/s",
+            "frac": dom["tflops"] / pinfo["peak"], "traffic": traffic if (B, L) == (512, 128) else None,
             "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "flops_per_launch": dom["flops"],
+            "algorithmic_bytes_per_launch": dom["bytes"],
         }
     result = {
         "metric": "backbones/sec (L=128, T=1000, bs=512)",
@@ -222,15 +241,15 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": pinfo["dtype"],
         "data": "synthetic",
         "config": {"workload": f"C2: released foldingdiff_cath shape (d=384,H=12,d_ff=768,12 layers,relative_key), "
                                f"L={L}, T={T}, batch {B}/GPU, synthetic HF-init weights, Philox noise, "
                                f"history {'off' if args.no_history else 'in HBM'}",
                    "global_batch": B * world, "seq_len": L, "timesteps": T, "parallelism": f"batch-shard x{world}",
-                   "fuse_ln": args.fuse_ln},
+                   "fuse_ln": args.fuse_ln, "gemm_precision": model.precision},
         "whole_step": {"algorithmic_tflops": value * flop_per_backbone / 1e12 / world,
-                       "frac_of_f32_mfma_peak": value * flop_per_backbone / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+                       "frac_of_mfma_peak": value * flop_per_backbone / 1e12 / world / pinfo["peak"],
                        "ms_per_timestep": elapsed / args.steps / T * 1e3},
         "roofline": roofline,
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),

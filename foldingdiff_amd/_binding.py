@@ -15,6 +15,8 @@ FD_OK = 0
 FD_POS = {"absolute": 0, "relative_key": 1, "relative_key_query": 2}
 FD_DEC = {"mlp": 0, "linear": 1}
 FD_PREC_F32 = 0
+FD_PREC_F16X3 = 1
+FD_PREC = {"f32": 0, "f16x3": 1}
 ABI_VERSION = 1
 
 
@@ -53,6 +55,7 @@ _SIGNATURES = {
     "fd_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_uint64, _P, C.c_int]),
     "fd_sample_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_uint64, C.c_int64, _P, C.c_int, _P]),
     "fd_philox_normal_dev": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    "fd_test_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "fd_profile_every": (C.c_int, [_P, C.c_int]),
     "fd_profile_reset": (C.c_int, [_P]),
     "fd_profile_count": (C.c_int, [_P]),

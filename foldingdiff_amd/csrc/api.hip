@@ -42,7 +42,14 @@ struct HostTensor {
   std::vector<int64_t> shape;
 };
 
+// split-precision image of one weight matrix (gemm_f16x3.hip)
+struct SplitW {
+  void* p = nullptr;
+  float scale = 1.f;
+};
+
 struct LayerDev {
+  SplitW wqkv_s, wo_s, wi_s, wd_s;
   float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
   float *wo = nullptr, *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr;
   float *wi = nullptr, *bi = nullptr, *wd = nullptr, *bd = nullptr, *ln2g = nullptr, *ln2b = nullptr;
@@ -96,6 +103,7 @@ struct fd_model {
   float *w_in = nullptr, *b_in = nullptr, *pos_emb = nullptr, *emb_g = nullptr, *emb_b = nullptr;
   std::vector<LayerDev> layers;
   float *hd_w1 = nullptr, *hd_b1 = nullptr, *hd_g = nullptr, *hd_b = nullptr, *hd_w2 = nullptr, *hd_b2 = nullptr;
+  SplitW hd_w1_s;
   float *coef = nullptr, *time_table = nullptr;
   // options
   int fuse_ln = 0;  // measured: the LN-fused GEMM (1 wave/SIMD) is slower than GEMM + LayerNorm kernel
@@ -124,6 +132,41 @@ int upload(fd_model* m, float** out, const float* src, size_t n) {
   int rc = dev_alloc(m, out, n);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(*out, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return FD_OK;
+}
+
+// W [N][K] fp32 -> [Npad128][K/16][hi x16 | lo x16] fp16 with w*scale = hi + lo (gemm_f16x3.hip).
+// scale = the power of two that puts max|w|*scale in [8192, 16384): every lo of a weight that
+// matters is a normal fp16 and nothing overflows.
+void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out, float* scale) {
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::fmax(mx, std::fabs(W[i]));
+  float s = 1.f;
+  if (mx > 0.f && std::isfinite(mx)) s = std::exp2(std::floor(std::log2(16384.0f / mx)));
+  *scale = s;
+  const int npad = (N + 127) / 128 * 128, nk = K / 16;
+  out->assign((size_t)npad * nk * 32, 0);
+  for (int n = 0; n < N; ++n)
+    for (int kt = 0; kt < nk; ++kt) {
+      uint16_t* dst = out->data() + ((size_t)n * nk + kt) * 32;
+      for (int j = 0; j < 16; ++j) {
+        const float xs = W[(size_t)n * K + kt * 16 + j] * s;
+        const _Float16 hi = (_Float16)xs;
+        const _Float16 lo = (_Float16)(xs - (float)hi);
+        memcpy(dst + j, &hi, 2);
+        memcpy(dst + 16 + j, &lo, 2);
+      }
+    }
+}
+
+int upload_split(fd_model* m, SplitW* dst, const float* W, int N, int K) {
+  std::vector<uint16_t> img;
+  pack_split_weight(W, N, K, &img, &dst->scale);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, img.size() * 2));
+  m->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  dst->p = p;
   return FD_OK;
 }
 
@@ -284,50 +327,57 @@ int harvest(fd_model* m) {
 
 // One reverse-diffusion step = BertForDiffusionBase.forward (modelling.py:384-484) + the
 // p_sample update and wrap (sampling.py:62-75, :119-130), as a fixed kernel sequence.
+void gemm(fd_model* m, int epi, const float* A, const float* W, const SplitW& Ws, const float* bias, const float* resid,
+          float* C, int M, int N, int K, hipStream_t s) {
+  if (m->precision == FD_PREC_F16X3) launch_gemm_f16x3(epi, A, Ws.p, Ws.scale, bias, resid, C, M, N, K, s);
+  else launch_gemm_f32(epi, A, W, bias, resid, C, M, N, K, s);
+}
+
 int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
   const fd_config& c = m->cfg;
   Workspace& w = m->ws;
   const int B = w.B, L = w.L, M = B * L, d = c.d_model, ff = c.d_ff, F = c.n_features;
+  const bool fuse_ln = m->fuse_ln && m->precision == FD_PREC_F32;
   PROF(KC_EMBED, launch_embed(w.x, m->w_in, m->b_in, m->pos_emb, m->emb_g, m->emb_b, c.ln_eps, m->time_table, w.t_dev,
                               w.h, B, L, F, d, s));
   for (int li = 0; li < c.n_layers; ++li) {
     const LayerDev& lw = m->layers[li];
-    PROF(KC_GEMM_QKV, launch_gemm_f32(EPI_BIAS, w.h, lw.wqkv, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
+    PROF(KC_GEMM_QKV, gemm(m, EPI_BIAS, w.h, lw.wqkv, lw.wqkv_s, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
     bool ok = true;
     PROF(KC_ATTN, ok = launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
     if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by this build (max 128)", L);
     bool fused = false;
-    if (m->fuse_ln)
+    if (fuse_ln)
       PROF(KC_GEMM_OUT, fused = launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
     if (!fused) {
-      if (m->fuse_ln && mode.profile) {  // the attempted launch recorded an empty bracket; drop it
+      if (fuse_ln && mode.profile) {  // the attempted launch recorded an empty bracket; drop it
         PendingEvent p = m->pending.back();
         m->pending.pop_back();
         m->event_pool.push_back(p.e0);
         m->event_pool.push_back(p.e1);
       }
-      PROF(KC_GEMM_OUT, launch_gemm_f32(EPI_BIAS_RESID, w.ctx, lw.wo, lw.bo, w.h, w.tmp, M, d, d, s));
+      PROF(KC_GEMM_OUT, gemm(m, EPI_BIAS_RESID, w.ctx, lw.wo, lw.wo_s, lw.bo, w.h, w.tmp, M, d, d, s));
       PROF(KC_LN1, launch_layernorm(w.tmp, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, s));
     }
-    PROF(KC_GEMM_UP, launch_gemm_f32(EPI_BIAS_GELU, w.a, lw.wi, lw.bi, nullptr, w.g, M, ff, d, s));
+    PROF(KC_GEMM_UP, gemm(m, EPI_BIAS_GELU, w.a, lw.wi, lw.wi_s, lw.bi, nullptr, w.g, M, ff, d, s));
     fused = false;
-    if (m->fuse_ln)
+    if (fuse_ln)
       PROF(KC_GEMM_DOWN, fused = launch_gemm_f32_ln(w.g, lw.wd, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s));
     if (!fused) {
-      if (m->fuse_ln && mode.profile) {
+      if (fuse_ln && mode.profile) {
         PendingEvent p = m->pending.back();
         m->pending.pop_back();
         m->event_pool.push_back(p.e0);
         m->event_pool.push_back(p.e1);
       }
-      PROF(KC_GEMM_DOWN, launch_gemm_f32(EPI_BIAS_RESID, w.g, lw.wd, lw.bd, w.a, w.tmp, M, d, ff, s));
+      PROF(KC_GEMM_DOWN, gemm(m, EPI_BIAS_RESID, w.g, lw.wd, lw.wd_s, lw.bd, w.a, w.tmp, M, d, ff, s));
       PROF(KC_LN2, launch_layernorm(w.tmp, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, s));
     }
   }
   UpdateArgs u;
   memset(&u, 0, sizeof u);
   if (c.decoder == FD_DEC_MLP) {
-    PROF(KC_GEMM_HEAD, launch_gemm_f32(EPI_BIAS_GELU, w.h, m->hd_w1, m->hd_b1, nullptr, w.g, M, d, d, s));
+    PROF(KC_GEMM_HEAD, gemm(m, EPI_BIAS_GELU, w.h, m->hd_w1, m->hd_w1_s, m->hd_b1, nullptr, w.g, M, d, d, s));
     u.g = w.g;
     u.gamma = m->hd_g;
     u.beta = m->hd_b;
@@ -399,7 +449,7 @@ int check_lens(const int32_t* lens, int B, int L) {
 
 int ensure_graph(fd_model* m) {
   Workspace& w = m->ws;
-  if (w.graph && w.graph_fuse_ln == m->fuse_ln) return FD_OK;
+  if (w.graph && w.graph_fuse_ln == m->fuse_ln) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
   if (w.graph) {
     (void)hipGraphExecDestroy(w.graph);
     w.graph = nullptr;
@@ -501,7 +551,7 @@ int fd_set_weight(fd_model* m, const char* name, const float* host_data, const i
 int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, const uint8_t* is_angle, int precision) {
   if (!m || !coef || !time_table || !is_angle) return fail(FD_E_INVALID, "null argument");
   if (T < 1) return fail(FD_E_INVALID, "T=%d", T);
-  if (precision != FD_PREC_F32) return fail(FD_E_UNSUPPORTED, "precision mode %d", precision);
+  if (precision != FD_PREC_F32 && precision != FD_PREC_F16X3) return fail(FD_E_UNSUPPORTED, "precision mode %d", precision);
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   m->ws.release();
@@ -542,6 +592,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     for (const HostTensor* t : {bq, bk, bv}) bqkv.insert(bqkv.end(), t->data.begin(), t->data.end());
     if (int rc = upload(m, &lw.wqkv, wqkv.data(), wqkv.size())) return rc;
     if (int rc = upload(m, &lw.bqkv, bqkv.data(), bqkv.size())) return rc;
+    if (precision == FD_PREC_F16X3)
+      if (int rc = upload_split(m, &lw.wqkv_s, wqkv.data(), 3 * (int)d, (int)d)) return rc;
     lw.demb = nullptr;
     if (c.pos_type == FD_POS_RELATIVE_KEY) {
       NEED(de, p + "attention.self.distance_embedding.weight");
@@ -559,6 +611,11 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     NEED(b2, p + "output.LayerNorm.bias");
     UP(lw.wo, wo); UP(lw.bo, bo); UP(lw.ln1g, g1); UP(lw.ln1b, b1);
     UP(lw.wi, wi); UP(lw.bi, bi); UP(lw.wd, wd); UP(lw.bd, bd); UP(lw.ln2g, g2); UP(lw.ln2b, b2);
+    if (precision == FD_PREC_F16X3) {
+      if (int rc = upload_split(m, &lw.wo_s, wo->data.data(), (int)d, (int)d)) return rc;
+      if (int rc = upload_split(m, &lw.wi_s, wi->data.data(), (int)ff, (int)d)) return rc;
+      if (int rc = upload_split(m, &lw.wd_s, wd->data.data(), (int)d, (int)ff)) return rc;
+    }
   }
   if (c.decoder == FD_DEC_MLP) {
     NEED(w1, "token_decoder.dense1.weight");
@@ -568,6 +625,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     NEED(w2, "token_decoder.dense2.weight");
     NEED(b2, "token_decoder.dense2.bias");
     UP(m->hd_w1, w1); UP(m->hd_b1, b1); UP(m->hd_g, g); UP(m->hd_b, b); UP(m->hd_w2, w2); UP(m->hd_b2, b2);
+    if (precision == FD_PREC_F16X3)
+      if (int rc = upload_split(m, &m->hd_w1_s, w1->data.data(), (int)d, (int)d)) return rc;
   } else {
     NEED(w2, "token_decoder.weight");
     NEED(b2, "token_decoder.bias");
@@ -575,7 +634,6 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
   }
 #undef NEED
 #undef UP
-  (void)ff;
   if (int rc = upload(m, &m->coef, coef, (size_t)4 * T)) return rc;
   if (int rc = upload(m, &m->time_table, time_table, (size_t)T * d)) return rc;
   m->angle_mask = 0;
@@ -748,6 +806,59 @@ int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, 
   launch_philox_fill(static_cast<float*>(out_dev), seed, t, seq_offset, B, L, m->cfg.n_features, s);
   HIP_TRY(hipGetLastError());
   return FD_OK;
+}
+
+int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, const float* W, const float* bias,
+                 const float* resid, float* C, int M, int N, int K) {
+  if (!A || !W || !bias || !C || M < 1 || N < 1 || K < 16 || K % 32) return fail(FD_E_INVALID, "bad argument");
+  if (epilogue < EPI_BIAS || epilogue > EPI_BIAS_RESID || (epilogue == EPI_BIAS_RESID && !resid))
+    return fail(FD_E_INVALID, "bad epilogue");
+  HIP_TRY(hipSetDevice(device_id));
+  float *dA = nullptr, *dW = nullptr, *db = nullptr, *dr = nullptr, *dC = nullptr;
+  void* dWp = nullptr;
+  float wscale = 1.f;
+  int rc = FD_OK;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)dA, (void*)dW, (void*)db, (void*)dr, (void*)dC, dWp})
+      if (p) (void)hipFree(p);
+  };
+#define T_TRY(expr)                                                          \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      cleanup();                                                             \
+      return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    }                                                                        \
+  } while (0)
+  T_TRY(hipMalloc((void**)&dA, (size_t)M * K * 4));
+  T_TRY(hipMalloc((void**)&dW, (size_t)N * K * 4));
+  T_TRY(hipMalloc((void**)&db, (size_t)N * 4));
+  T_TRY(hipMalloc((void**)&dC, (size_t)M * N * 4));
+  T_TRY(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+  T_TRY(hipMemcpy(dW, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
+  T_TRY(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+  if (resid) {
+    T_TRY(hipMalloc((void**)&dr, (size_t)M * N * 4));
+    T_TRY(hipMemcpy(dr, resid, (size_t)M * N * 4, hipMemcpyHostToDevice));
+  }
+  if (precision == FD_PREC_F16X3) {
+    std::vector<uint16_t> img;
+    pack_split_weight(W, N, K, &img, &wscale);
+    T_TRY(hipMalloc(&dWp, img.size() * 2));
+    T_TRY(hipMemcpy(dWp, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    launch_gemm_f16x3(epilogue, dA, dWp, wscale, db, dr, dC, M, N, K, nullptr);
+  } else if (precision == FD_PREC_F32) {
+    launch_gemm_f32(epilogue, dA, dW, db, dr, dC, M, N, K, nullptr);
+  } else {
+    cleanup();
+    return fail(FD_E_INVALID, "precision %d", precision);
+  }
+  T_TRY(hipGetLastError());
+  T_TRY(hipDeviceSynchronize());
+  T_TRY(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+#undef T_TRY
+  cleanup();
+  return rc;
 }
 
 int fd_profile_every(fd_model* m, int n) {

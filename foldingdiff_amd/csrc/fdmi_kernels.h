@@ -20,6 +20,12 @@ enum GemmEpilogue {
 void launch_gemm_f32(int epilogue, const float* A, const float* W, const float* bias, const float* resid, float* C,
                      int M, int N, int K, hipStream_t s);
 
+// fp16x3 split-precision GEMM (three v_mfma_f32_32x32x16_f16 per product, fp32-class accuracy).
+// Wp: weight pre-split by pack_split_weight() (host) into [Npad128][K/16][hi x16 | lo x16] fp16,
+// scaled by the power of two w_scale.  K % 16 == 0.
+void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
+                       const float* resid, float* C, int M, int N, int K, hipStream_t s);
+
 // Fused GEMM + bias + residual + LayerNorm over full rows (N == 384 or 192):
 //   C = LN(A * W^T + bias + resid) * gamma + beta.   Returns false if (N) has no instantiation.
 bool launch_gemm_f32_ln(const float* A, const float* W, const float* bias, const float* resid, const float* gamma,

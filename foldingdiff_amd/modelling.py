@@ -33,6 +33,7 @@ import torch
 from . import _binding, beta_schedules
 from .datasets import FEATURE_SET_NAMES_TO_ANGULARITY
 
+DEFAULT_PRECISION = "f32"
 TIME_ENCODING = Literal["gaussian_fourier", "sinusoidal"]
 DECODER_HEAD = Literal["mlp", "linear"]
 
@@ -163,6 +164,9 @@ class BertForDiffusionBase:
             raise NotImplementedError(f"hidden_act={config.hidden_act!r}: only exact-erf 'gelu' is implemented")
         self.time_encoding = time_encoding
         self.decoder = decoder
+        # arithmetic of the GEMM kernels: "f32" (exact fp32 MFMA) or "f16x3" (fp16 hi/lo split
+        # on the fp16 MFMA, fp32-class error); env FOLDINGDIFF_AMD_PRECISION overrides the default
+        self.precision = os.environ.get("FOLDINGDIFF_AMD_PRECISION", DEFAULT_PRECISION)
         self.training = False
         self._device = torch.device("cpu")
         self._handle = None          # fd_model* on self._device
@@ -349,7 +353,9 @@ class BertForDiffusionBase:
         elif isinstance(is_angle, bool):
             is_angle = [is_angle] * self.n_inputs
         assert len(is_angle) == self.n_inputs
-        key = (betas.numel(), betas.numpy().tobytes(), tuple(bool(a) for a in is_angle))
+        if self.precision not in _binding.FD_PREC:
+            raise ValueError(f"precision={self.precision!r}; expected one of {sorted(_binding.FD_PREC)}")
+        key = (betas.numel(), betas.numpy().tobytes(), tuple(bool(a) for a in is_angle), self.precision)
         if self._betas_key == key:
             return h
         T = betas.numel()
@@ -358,10 +364,20 @@ class BertForDiffusionBase:
         is_angle = np.ascontiguousarray(np.asarray(is_angle, dtype=np.uint8))
         _binding.check(_binding.load().fd_finalize(
             h, T, coef.ctypes.data_as(C.c_void_p), table.ctypes.data_as(C.c_void_p),
-            is_angle.ctypes.data_as(C.c_void_p), _binding.FD_PREC_F32))
+            is_angle.ctypes.data_as(C.c_void_p), _binding.FD_PREC[self.precision]))
         self._betas_key = key
         self._tables_T = T
         return h
+
+    def set_precision(self, precision: str):
+        """Select the GEMM arithmetic ("f32" | "f16x3"); takes effect at the next prepare()."""
+        if precision not in _binding.FD_PREC:
+            raise ValueError(f"precision={precision!r}; expected one of {sorted(_binding.FD_PREC)}")
+        if precision != self.precision:
+            self.precision = precision
+            self._betas_key = None
+            self._tables_T = None
+        return self
 
     def set_option(self, name: str, value: int):
         _binding.check(_binding.load().fd_set_option(self._ensure_handle(), name.encode(), int(value)))

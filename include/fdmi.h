@@ -48,7 +48,10 @@ enum { FD_POS_ABSOLUTE = 0, FD_POS_RELATIVE_KEY = 1, FD_POS_RELATIVE_KEY_QUERY =
 enum { FD_DEC_MLP = 0, FD_DEC_LINEAR = 1 };
 /* arithmetic of the contraction kernels */
 enum {
-  FD_PREC_F32 = 0 /* v_mfma_f32_32x32x2_f32: exact fp32 products + fp32 accumulate (parity path) */
+  FD_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products + fp32 accumulate */
+  FD_PREC_F16X3 = 1 /* GEMM operands split into fp16 hi + lo (22 significant bits), three
+                       v_mfma_f32_32x32x16_f16 per product, fp32 accumulate: fp32-class error at
+                       5.3x the fp32-MFMA rate.  Attention / LayerNorm / softmax / GELU stay fp32. */
 };
 
 typedef struct fd_model fd_model;
@@ -150,6 +153,13 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
  * t of a [B][L][F] batch -- exposes the perf-mode generator for tests. */
 int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, int B, int L, void* out_dev,
                          void* hip_stream);
+
+/* ---- test hook ----
+ * One token GEMM  C[M,N] = A[M,K] W[N,K]^T + bias (+GELU | +resid) through the production
+ * kernels of the given precision (epilogue: 0 bias, 1 bias+GELU, 2 bias+residual).  Host buffers,
+ * K % 32 == 0.  Used by tests/ to measure kernel error against fp64 in isolation. */
+int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, const float* W, const float* bias,
+                 const float* resid, float* C, int M, int N, int K);
 
 /* ---- measurement ---- */
 

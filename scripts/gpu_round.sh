@@ -13,19 +13,19 @@ timeout 1200 python -m pytest tests -q -m gpu --durations=8 -p no:cacheprovider 
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.log
 echo "== bench"
-timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 2>&1 | tail -3 | tee $OUT/bench.log
-if [ "${WITH_FUSED:-1}" = "1" ]; then
-  timeout 600 python bench.py --steps 1 --warmup 1 --fuse-ln 1 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_fusedln.log
+timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 ${BENCH_ARGS:-} 2>&1 | tail -3 | tee $OUT/bench.log
+if [ -n "${BENCH2_ARGS:-}" ]; then
+  timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline $BENCH2_ARGS 2>&1 | tail -1 | tee $OUT/bench2.log
 fi
 if [ "${WITH_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel-trace --stats (same command as the bench, T=${PROF_T:-200})"
   R=$PWD
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 1 --warmup 0 --timesteps ${PROF_T:-200} --no-cpu-baseline > $R/$OUT/prof_run.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 1 --warmup 0 --timesteps ${PROF_T:-200} --no-cpu-baseline ${BENCH_ARGS:-} > $R/$OUT/prof_run.log 2>&1
   tail -1 $R/$OUT/prof_run.log | cut -c1-400
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== rocprofv3 --pmc $c (eager launches, T=4)"
-    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 4 --profile-every 0 --no-cpu-baseline > $R/$OUT/pmc_$c.log 2>&1
+    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 4 --profile-every 0 --no-cpu-baseline ${BENCH_ARGS:-} > $R/$OUT/pmc_$c.log 2>&1
     tail -1 $R/$OUT/pmc_$c.log | cut -c1-200
   done
   cd $R
