@@ -108,6 +108,7 @@ struct fd_model {
   // options
   int fuse_ln = 0;  // measured: the LN-fused GEMM (1 wave/SIMD) is slower than GEMM + LayerNorm kernel
   int use_graph = 1;
+  int attn_f16 = 1;  // with FD_PREC_F16X3: attention on the fp16x3 kernel (0: keep the fp32-MFMA one)
   Workspace ws;
   // profiling
   int profile_every = 0;
@@ -135,7 +136,7 @@ int upload(fd_model* m, float** out, const float* src, size_t n) {
   return FD_OK;
 }
 
-// W [N][K] fp32 -> [Npad128][K/16][hi x16 | lo x16] fp16 with w*scale = hi + lo (gemm_f16x3.hip).
+// W [N][K] fp32 -> [Npad128][K/32][hi x32 | lo x32] fp16 with w*scale = hi + lo (gemm_f16x3.hip).
 // scale = the power of two that puts max|w|*scale in [8192, 16384): every lo of a weight that
 // matters is a normal fp16 and nothing overflows.
 void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out, float* scale) {
@@ -144,17 +145,17 @@ void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out,
   float s = 1.f;
   if (mx > 0.f && std::isfinite(mx)) s = std::exp2(std::floor(std::log2(16384.0f / mx)));
   *scale = s;
-  const int npad = (N + 127) / 128 * 128, nk = K / 16;
-  out->assign((size_t)npad * nk * 32, 0);
+  const int npad = (N + 127) / 128 * 128, nk = K / 32;
+  out->assign((size_t)npad * nk * 64, 0);
   for (int n = 0; n < N; ++n)
     for (int kt = 0; kt < nk; ++kt) {
-      uint16_t* dst = out->data() + ((size_t)n * nk + kt) * 32;
-      for (int j = 0; j < 16; ++j) {
-        const float xs = W[(size_t)n * K + kt * 16 + j] * s;
+      uint16_t* dst = out->data() + ((size_t)n * nk + kt) * 64;
+      for (int j = 0; j < 32; ++j) {
+        const float xs = W[(size_t)n * K + kt * 32 + j] * s;
         const _Float16 hi = (_Float16)xs;
         const _Float16 lo = (_Float16)(xs - (float)hi);
         memcpy(dst + j, &hi, 2);
-        memcpy(dst + 16 + j, &lo, 2);
+        memcpy(dst + 32 + j, &lo, 2);
       }
     }
 }
@@ -344,7 +345,9 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
     const LayerDev& lw = m->layers[li];
     PROF(KC_GEMM_QKV, gemm(m, EPI_BIAS, w.h, lw.wqkv, lw.wqkv_s, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
     bool ok = true;
-    PROF(KC_ATTN, ok = launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
+    PROF(KC_ATTN, ok = (m->precision == FD_PREC_F16X3 && m->attn_f16)
+                        ? launch_attention_f16x3(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s)
+                        : launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
     if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by this build (max 128)", L);
     bool fused = false;
     if (fuse_ln)
@@ -665,6 +668,10 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   const std::string n = name;
   if (n == "fuse_ln") m->fuse_ln = value ? 1 : 0;
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
+  else if (n == "attn_f16") {
+    m->attn_f16 = value ? 1 : 0;
+    m->ws.graph_fuse_ln = -1;  // force a re-capture
+  }
   else return fail(FD_E_INVALID, "unknown option '%s'", name);
   return FD_OK;
 }

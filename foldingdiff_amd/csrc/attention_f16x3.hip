@@ -1,0 +1,349 @@
+// Multi-head self-attention (HF BertSelfAttention 4.11.3 semantics incl. relative_key and the
+// additive -10000 key mask; see attention_f32.hip for the math and citations) with the three
+// contractions on the fp16 matrix cores at fp32-class accuracy: every operand x is split
+// x*s = hi + lo (fp16 each, s a power of two) and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is
+// issued as three v_mfma_f32_32x32x16_f16 into one fp32 accumulator (see gemm_f16x3.hip).
+//
+// One 8-wave workgroup per (sequence, pair of heads); a wave owns 32-query row blocks.
+//   LDS (fp16 hi|lo row images, rows padded so the 16/8-byte operand fetches are conflict free):
+//     K   [2 heads][LP keys][hi d0-31 | lo d0-31]      144 B rows
+//     E   [2*LP band rows][hi | lo]                     144 B rows   (relative_key only; shared by both heads)
+//     Vt  [2 heads][32 d][hi key0..LP-1 | lo ...]       transposed while filling: keys contiguous
+//     Rw  [8 waves][32 queries][32 fp32 (+4 pad)]       scratch for the relative-key skew
+//   * S^T tile (keys x queries) = K . Q^T : A = K rows (LDS), B = Q (registers).  The transposed
+//     form puts a query's scores in ONE lane pair: softmax max/sum are in-register reductions
+//     plus a single cross-half shuffle, and P is already laid out as the A operand of P.V
+//     (the k <-> (step, half, j) assignment of an MFMA is free as long as A and B agree:
+//     key(c, half, j) = 16c + 8(j>>2) + 4*half + (j&3), which is exactly the C/D row map).
+//   * R tile (queries x band) = Q . E^T, same Q registers as A operand.  The Toeplitz skew
+//     S^T[r, l] += R[l, l - r + c] transposes queries from registers to lanes, so R goes through
+//     the wave's LDS scratch one 32x32 tile at a time and is read back with per-lane addresses
+//     (row l = lane, column l - r + const: bank = 5*lane mod 32, conflict free).
+//   * O = P . V : A = P (registers, split to fp16 hi/lo after the softmax), B = Vt (LDS).
+// Scores, probabilities and the context accumulate in fp32; nothing but q|k|v and ctx touches HBM.
+#include "fdmi_kernels.h"
+
+namespace fdmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace a16 {
+
+constexpr int HPB = 2;          // heads per workgroup
+constexpr int KROW = 144;       // bytes per K / E row image: 64 B hi + 64 B lo + 16 B pad
+constexpr int RLD = 36;         // floats per row of the R scratch
+constexpr float QS = 16.0f;     // power-of-two operand scales (exact); undone in fp32 after the MFMAs
+constexpr float KS = 16.0f;
+constexpr float ES = 1024.0f;   // distance-embedding rows are ~0.02 in magnitude
+constexpr float PS = 1024.0f;   // probabilities are <= 1
+constexpr float VS = 16.0f;
+
+__device__ __forceinline__ float exp_neg(float x) {
+  const float LOG2E_HI = 1.44269502162933349609375f, LOG2E_LO = 1.925963033500011e-08f;
+  x = fmaxf(x, -200.0f);
+  const float t = x * LOG2E_HI;
+  const float err = fmaf(x, LOG2E_HI, -t) + x * LOG2E_LO;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, err * 0.693147180559945f, e);
+}
+
+__device__ __forceinline__ void split1(float x, float s, _Float16& hi, _Float16& lo) {
+  const float xs = x * s;
+  hi = (_Float16)xs;
+  lo = (_Float16)(xs - (float)hi);
+}
+
+__device__ __forceinline__ void split8(const float4& p, const float4& q, float s, f16x8& hi, f16x8& lo) {
+  const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    _Float16 h, l;
+    split1(x[i], s, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+
+template <int T, bool REL>
+__global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __restrict__ qkv,
+                                                               const float* __restrict__ demb,
+                                                               const int* __restrict__ lens, float* __restrict__ ctx,
+                                                               int L, int H, int maxpos) {
+  constexpr int LP = 32 * T;
+  constexpr int NT = 256 * HPB;
+  constexpr int VROW = 4 * LP + 8;  // bytes per Vt row: LP hi + LP lo halves + 8 B pad (b64 reads conflict free)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  unsigned char* Ks = smem16;                               // [HPB][LP] rows of KROW bytes
+  unsigned char* Es = Ks + HPB * LP * KROW;                 // [2*LP] rows of KROW bytes (REL only)
+  unsigned char* Vt = Es + (REL ? 2 * LP * KROW : 0);       // [HPB][32] rows of VROW bytes
+  float* Rs = reinterpret_cast<float*>(Vt + HPB * 32 * VROW);  // [4*HPB waves][32][RLD]   (REL only)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int hgroups = (H + HPB - 1) / HPB;
+  const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * HPB;
+  const int d = H * 32, ld = 3 * d;
+  const int len = lens[b];
+  const float* seq = qkv + (size_t)b * L * ld;
+
+  // ---- fill K (row images) : one thread per (head, key, 8-wide d octet)
+  for (int idx = tid; idx < HPB * LP * 4; idx += NT) {
+    const int hh = idx / (LP * 4), rem = idx % (LP * 4);
+    const int r = rem >> 2, oct = rem & 3;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+    if (r < L && h0 + hh < H) {
+      const float* src = seq + (size_t)r * ld + d + (h0 + hh) * 32 + oct * 8;
+      p = *reinterpret_cast<const float4*>(src);
+      q = *reinterpret_cast<const float4*>(src + 4);
+    }
+    f16x8 hi, lo;
+    split8(p, q, KS, hi, lo);
+    unsigned char* row = Ks + (size_t)(hh * LP + r) * KROW;
+    *reinterpret_cast<u32x4*>(row + oct * 16) = __builtin_bit_cast(u32x4, hi);
+    *reinterpret_cast<u32x4*>(row + 64 + oct * 16) = __builtin_bit_cast(u32x4, lo);
+  }
+  // ---- fill Vt (transposed): one thread per (head, key pair, 4-wide d group)
+  for (int idx = tid; idx < HPB * (LP / 2) * 8; idx += NT) {
+    const int hh = idx / ((LP / 2) * 8), rem = idx % ((LP / 2) * 8);
+    const int kp = rem >> 3, c4 = rem & 7;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (h0 + hh < H) {
+      const float* src = seq + 2 * d + (h0 + hh) * 32 + c4 * 4;
+      if (2 * kp < L) v0 = *reinterpret_cast<const float4*>(src + (size_t)(2 * kp) * ld);
+      if (2 * kp + 1 < L) v1 = *reinterpret_cast<const float4*>(src + (size_t)(2 * kp + 1) * ld);
+    }
+    const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x2 hi, lo;
+      _Float16 h, l;
+      split1(a0[i], VS, h, l); hi[0] = h; lo[0] = l;
+      split1(a1[i], VS, h, l); hi[1] = h; lo[1] = l;
+      unsigned char* row = Vt + (size_t)(hh * 32 + c4 * 4 + i) * VROW;
+      *reinterpret_cast<unsigned*>(row + 4 * kp) = __builtin_bit_cast(unsigned, hi);
+      *reinterpret_cast<unsigned*>(row + 2 * LP + 4 * kp) = __builtin_bit_cast(unsigned, lo);
+    }
+  }
+  if constexpr (REL) {
+    // Es[e] = E[m_min + e], m_min = (maxpos-1) - (LP-1); rows outside the table are zero
+    const int m_min = (maxpos - 1) - (LP - 1);
+    for (int idx = tid; idx < 2 * LP * 4; idx += NT) {
+      const int e = idx >> 2, oct = idx & 3, m = e + m_min;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+      if (m >= 0 && m <= 2 * (maxpos - 1)) {
+        const float* src = demb + (size_t)m * 32 + oct * 8;
+        p = *reinterpret_cast<const float4*>(src);
+        q = *reinterpret_cast<const float4*>(src + 4);
+      }
+      f16x8 hi, lo;
+      split8(p, q, ES, hi, lo);
+      unsigned char* row = Es + (size_t)e * KROW;
+      *reinterpret_cast<u32x4*>(row + oct * 16) = __builtin_bit_cast(u32x4, hi);
+      *reinterpret_cast<u32x4*>(row + 64 + oct * 16) = __builtin_bit_cast(u32x4, lo);
+    }
+  }
+  __syncthreads();
+
+  const int hh = wid >> 2, wq = wid & 3, h = h0 + hh;
+  if (h >= H) return;
+  const float* base = seq + h * 32;
+  const unsigned char* Kh = Ks + (size_t)hh * LP * KROW;
+  const unsigned char* Vh = Vt + (size_t)hh * 32 * VROW;
+  float* Rw = Rs + wid * 32 * RLD;
+  const int nrb = (L + 31) >> 5;
+  for (int rb = wq; rb < nrb; rb += 4) {
+    const int l0 = rb * 32;
+    // Q operand: lane (query l31, half) holds d = 16c + 8*half + j   (B of K.Q^T and A of Q.E^T alike)
+    f16x8 qh[2], ql[2];
+    {
+      const int l = l0 + l31;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+        if (l < L) {
+          const float* src = base + (size_t)l * ld + 16 * c + 8 * half;
+          p = *reinterpret_cast<const float4*>(src);
+          q = *reinterpret_cast<const float4*>(src + 4);
+        }
+        split8(p, q, QS, qh[c], ql[c]);
+      }
+    }
+    // S^T tiles: rows = keys 32t + rowmap(r, half), cols = queries l0 + l31
+    f32x16 sacc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+      const unsigned char* row = Kh + (size_t)(32 * t + l31) * KROW;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 32 * c + 16 * half));
+        const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 64 + 32 * c + 16 * half));
+        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
+        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
+        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+      }
+    }
+    constexpr float S_SCALE = 1.0f / (QS * KS);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t][r] *= S_SCALE;
+    if constexpr (REL) {
+      // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31, i.e.
+      // m = m_min + l0 + 32q + l31.  S^T tile t element (key kl, query ql) needs band column
+      // j = ql - kl + 31 of the tile pair (q = T-1-t, q+1):  j < 32 -> tile q, else tile q+1 col j-32.
+      constexpr float R_SCALE = 1.0f / (QS * ES);
+#pragma unroll
+      for (int q = 0; q <= T; ++q) {
+        f32x16 racc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+        const unsigned char* row = Es + (size_t)(l0 + 32 * q + l31) * KROW;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const f16x8 eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 32 * c + 16 * half));
+          const f16x8 el = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 64 + 32 * c + 16 * half));
+          racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], eh, racc, 0, 0, 0);
+          racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], el, racc, 0, 0, 0);
+          racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[c], eh, racc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r] * R_SCALE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // scratch row = query l31 (this lane); gather into the two S^T tiles that use band tile q
+        if (q < T) {  // as the low tile of S^T tile t = T-1-q : j = l31 - kl + 31 <= 31  <=>  l31 <= kl
+          const int t = T - 1 - q;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int j = l31 - kl + 31;
+            const float v = Rw[l31 * RLD + (j & 31)];
+            if (j < 32) sacc[t][r] += v;
+          }
+        }
+        if (q > 0) {  // as the high tile of S^T tile t = T-q : column j - 32 = l31 - kl - 1 >= 0
+          const int t = T - q;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int j = l31 - kl + 31;
+            const float v = Rw[l31 * RLD + (j & 31)];
+            if (j >= 32) sacc[t][r] += v;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // scale, mask, softmax over keys: this lane + its partner (lane ^ 32) hold one query's scores
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float s = sacc[t][r] * 0.17677669529663687f;  // / sqrt(attention_head_size = 32)
+        if (key >= len) s += -10000.0f;               // (1 - mask) * -10000   (modelling.py:452)
+        if (key >= L) s = -INFINITY;                  // tile padding: not a key at all
+        sacc[t][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pexp = exp_neg(sacc[t][r] - mx);
+        sacc[t][r] = pexp;
+        sum += pexp;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = PS / sum;  // probabilities carried scaled by PS into the fp16 split
+    // O = P V:  A[i = query l31][position (c, half, j)] = P[key 32t + 16c + 8(j>>2) + 4half + (j&3)] = sacc[t][8c + j]
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    const unsigned char* vrow = Vh + (size_t)l31 * VROW;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xs = sacc[t][8 * c + j] * inv;
+          const _Float16 hv = (_Float16)xs;
+          ph[j] = hv;
+          pl[j] = (_Float16)(xs - (float)hv);
+        }
+        // V operand: keys 32t + 16c + 4half + {0..3} and + 8 : two 8-byte reads per plane
+        const int kb = 2 * (32 * t + 16 * c + 4 * half);
+        const u32x2 vh0 = *reinterpret_cast<const u32x2*>(vrow + kb);
+        const u32x2 vh1 = *reinterpret_cast<const u32x2*>(vrow + kb + 16);
+        const u32x2 vl0 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb);
+        const u32x2 vl1 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb + 16);
+        const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
+        const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
+        const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oacc, 0, 0, 0);
+      }
+    constexpr float O_SCALE = 1.0f / (PS * VS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int l = l0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (l < L) ctx[((size_t)b * L + l) * d + h * 32 + l31] = oacc[r] * O_SCALE;
+    }
+  }
+}
+
+template <int T, bool REL>
+static void launch_t(const float* qkv, const float* demb, const int* lens, float* ctx, int B, int L, int H, int maxpos,
+                     hipStream_t s) {
+  constexpr int LP = 32 * T;
+  const size_t smem = (size_t)HPB * LP * KROW + (REL ? 2 * LP * KROW : 0) + (size_t)HPB * 32 * (4 * LP + 8) +
+                      (REL ? sizeof(float) * 4 * HPB * 32 * RLD : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int hgroups = (H + HPB - 1) / HPB;
+  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL>), dim3(B * hgroups), dim3(256 * HPB), smem, s, qkv, demb, lens, ctx, L,
+                     H, maxpos);
+}
+
+}  // namespace a16
+
+bool launch_attention_f16x3(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
+                            int maxpos, hipStream_t s) {
+  if (L < 1 || L > 128) return false;
+  const int T = (L + 31) / 32;
+  const bool rel = dist_emb != nullptr;
+#define FD_ATTN16_CASE(TT)                                                             \
+  case TT:                                                                             \
+    if (rel) a16::launch_t<TT, true>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);    \
+    else a16::launch_t<TT, false>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);       \
+    break;
+  switch (T) {
+    FD_ATTN16_CASE(1)
+    FD_ATTN16_CASE(2)
+    FD_ATTN16_CASE(3)
+    FD_ATTN16_CASE(4)
+  }
+#undef FD_ATTN16_CASE
+  return true;
+}
+
+}  // namespace fdmi

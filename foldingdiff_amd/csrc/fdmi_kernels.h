@@ -21,8 +21,8 @@ void launch_gemm_f32(int epilogue, const float* A, const float* W, const float* 
                      int M, int N, int K, hipStream_t s);
 
 // fp16x3 split-precision GEMM (three v_mfma_f32_32x32x16_f16 per product, fp32-class accuracy).
-// Wp: weight pre-split by pack_split_weight() (host) into [Npad128][K/16][hi x16 | lo x16] fp16,
-// scaled by the power of two w_scale.  K % 16 == 0.
+// Wp: weight pre-split by pack_split_weight() (host) into [Npad128][K/32][hi x32 | lo x32] fp16,
+// scaled by the power of two w_scale.  K % 32 == 0.
 void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
                        const float* resid, float* C, int M, int N, int K, hipStream_t s);
 
@@ -46,6 +46,10 @@ void launch_embed(const float* x, const float* w_in, const float* b_in, const fl
 // Returns false when L is beyond what this build tiles (L > 128).
 bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
                           int maxpos, hipStream_t s);
+
+// Same contract, contractions as fp16 hi/lo split triples on v_mfma_f32_32x32x16_f16 (fp32-class accuracy).
+bool launch_attention_f16x3(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
+                            int maxpos, hipStream_t s);
 
 // K8 tail + K9: per token  y = do_ln ? LN(g)*gamma+beta : g ;  eps = y W2^T + b2 ;
 //   x' = wrap_if_angle( c1[t] * (x - beta[t]*eps / c3[t]) + (t>0 ? sigma[t]*z : 0) )

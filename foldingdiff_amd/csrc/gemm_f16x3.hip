@@ -18,12 +18,15 @@
 //
 // Activations stay fp32 in HBM; they are split while being staged into LDS (VALU work that
 // overlaps the MFMAs).  Weights are split once at fd_finalize into the LDS row image
-// [n][k/16][hi x16 | lo x16] (64 B).
+// [n][k/32][hi x32 | lo x32] (128 B).
 //
-// Tiling: 256 x 128 block, 4 waves as 2 x 2, each 128 x 64 (4 x 2 MFMA tiles, 128 accumulator
-// registers), BK = 16, LDS double buffered (one barrier per k-tile).  LDS rows
-// are 64 B of payload padded to 80 B => the 16-byte operand fetches are conflict free.
-// 32 FLOP per staged byte -> 21 B/clk/CU from L2 at the fp16x3 peak (tile sized for that).
+// Tiling: 256 x 128 block, 8 waves as 4 x 2, each 64 x 64 (2 x 2 MFMA tiles, 64 accumulator
+// registers), BK = 32, LDS double buffered (one barrier per k-tile), and TWO k-tiles of global
+// loads in flight per thread (register prefetch sets): the kernel is L2-latency bound with one.
+// LDS rows are 128 B of payload [hi k0-31 | lo k0-31] padded to 144 B => the 16-byte operand
+// fetches are conflict free.  32 FLOP per staged byte -> 21 B/clk/CU from L2 at the fp16x3 peak.
+#include <cstdlib>
+
 #include "fdmi_kernels.h"
 
 namespace fdmi {
@@ -34,7 +37,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // 16-byte LDS / gl
 
 struct GemmSplitArgs {
   const float* A;
-  const u32x4* Wp;  // packed split weight, [Npad][K/16][4] x 16 B
+  const u32x4* Wp;  // packed split weight, [Npad128][K/32][8] x 16 B  (hi k0-31 | lo k0-31)
   const float* bias;
   const float* resid;
   float* C;
@@ -67,11 +70,12 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
   lo = __builtin_bit_cast(u32x4, b);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p) {
-  constexpr int BM = 256, BN = 128, BK = 16, RQ = 5;  // RQ: uint4 (16 B) per padded LDS row
+template <int EPI, int PF>
+__global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
+  constexpr int BM = 256, BN = 128, BK = 32, RQ = 9;  // RQ: 16-byte units per padded LDS row (144 B)
   constexpr int STAGE = (BM + BN) * RQ;
-  __shared__ u32x4 smem[2 * STAGE];  // 2 x 30,720 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);  // 2 stages x 55,296 B
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -81,84 +85,103 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p) {
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   const int K = p.K, nk = K / BK;
 
-  f32x16 acc[4][2];
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging roles: thread t owns A row t (16 floats = 64 B per k-tile); W image chunks 2 per thread
-  float4 ra[4];
-  u32x4 rw[2];
-  const int arow = m0 + tid;
-  const float* aptr = p.A + (size_t)(arow < p.M ? arow : 0) * K;
-  auto gload = [&](int kt) {
+  // staging roles: thread t -> A row t/2, 16 floats (k = 16*(t&1) ..); W row t/4, 32 B of its image
+  const int arow = tid >> 1, au = tid & 1;
+  const bool a_ok = m0 + arow < p.M;
+  const float* aptr = p.A + (size_t)(a_ok ? m0 + arow : 0) * K + 16 * au;
+  const int wrow = tid >> 2, wpart = 2 * (tid & 3);
+  const u32x4* wptr = p.Wp + ((size_t)(n0 + wrow) * nk) * 8 + wpart;
+
+  float4 ra0[4], ra1[4];
+  u32x4 rw0[2], rw1[2];
+  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[2], int kt) {
+    if (kt >= nk) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ra[i] = arow < p.M ? *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i, row = c >> 2, part = c & 3;
-      rw[i] = p.Wp[((size_t)(n0 + row) * nk + kt) * 4 + part];
-    }
+      ra[i] = a_ok ? *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rw[0] = wptr[(size_t)kt * 8];
+    rw[1] = wptr[(size_t)kt * 8 + 1];
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[2], int buf) {
     u32x4* S = smem + buf * STAGE;
     u32x4 h0, l0, h1, l1;
     split8(ra[0], ra[1], p.a_scale, h0, l0);
     split8(ra[2], ra[3], p.a_scale, h1, l1);
-    u32x4* row = S + tid * RQ;  // [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15 | pad]
-    row[0] = h0; row[1] = h1; row[2] = l0; row[3] = l1;
+    u32x4* row = S + arow * RQ;  // [hi k0-31 (4 units) | lo k0-31 (4 units) | pad]
+    row[2 * au] = h0; row[2 * au + 1] = h1; row[4 + 2 * au] = l0; row[4 + 2 * au + 1] = l1;
+    u32x4* wr = S + (BM + wrow) * RQ + wpart;
+    wr[0] = rw[0];
+    wr[1] = rw[1];
+  };
+  auto compute = [&](int buf) {
+    const u32x4* S = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i, r = c >> 2, part = c & 3;
-      S[(BM + r) * RQ + part] = rw[i];
+    for (int c = 0; c < 2; ++c) {  // two k16 steps
+      f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4* row = S + (wm * 64 + i * 32 + l31) * RQ;
+        ah[i] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+        al[i] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x4* row = S + (BM + wn * 64 + j * 32 + l31) * RQ;
+        bh[j] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+        bl[j] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
     }
   };
 
-  gload(0);
-  lstore(0);
-  if (nk > 1) gload(1);
+  // register set 1 carries the even k-tiles, set 0 the odd ones
+  gload(ra1, rw1, 0);
+  lstore(ra1, rw1, 0);
+  gload(ra0, rw0, 1);
+  if constexpr (PF == 2) gload(ra1, rw1, 2);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const u32x4* S = smem + (kt & 1) * STAGE;
-    f16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x4* row = S + (wm * 128 + i * 32 + l31) * RQ;
-      ah[i] = __builtin_bit_cast(f16x8, row[half]);
-      al[i] = __builtin_bit_cast(f16x8, row[2 + half]);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const u32x4* row = S + (BM + wn * 64 + j * 32 + l31) * RQ;
-      bh[j] = __builtin_bit_cast(f16x8, row[half]);
-      bl[j] = __builtin_bit_cast(f16x8, row[2 + half]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even tile kt is in buffer 0; stage odd tile kt+1 into buffer 1 (last read in iteration
+    // kt-1: every wave has passed that barrier)
+    compute(0);
     if (kt + 1 < nk) {
-      lstore((kt + 1) & 1);  // buffer last read in iteration kt-1; every wave passed that barrier
-      if (kt + 2 < nk) gload(kt + 2);
+      lstore(ra0, rw0, 1);
+      if constexpr (PF == 2) gload(ra0, rw0, kt + 3);
+      else gload(ra1, rw1, kt + 2);
+    }
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    compute(1);
+    if (kt + 2 < nk) {
+      lstore(ra1, rw1, 0);
+      if constexpr (PF == 2) gload(ra1, rw1, kt + 4);
+      else gload(ra0, rw0, kt + 3);
     }
     __syncthreads();
   }
 
   // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + l31;
@@ -166,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p) {
         const float bz = p.bias[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (row < p.M) {
             float v = acc[i][j][r] * p.out_scale + bz;
             if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf16(v);
@@ -178,16 +201,43 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p) {
     }
 }
 
+constexpr int kSplitSmem = 2 * (256 + 128) * 9 * 16;  // 110,592 B
+
+template <int EPI, int PF>
+static void launch_one(const GemmSplitArgs& p, int tiles, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<EPI, PF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kSplitSmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, PF>), dim3(tiles), dim3(512), kSplitSmem, s, p);
+}
+
+template <int PF>
+static void launch_pf(int epilogue, const GemmSplitArgs& p, int tiles, hipStream_t s) {
+  switch (epilogue) {
+    case EPI_BIAS: launch_one<EPI_BIAS, PF>(p, tiles, s); break;
+    case EPI_BIAS_GELU: launch_one<EPI_BIAS_GELU, PF>(p, tiles, s); break;
+    default: launch_one<EPI_BIAS_RESID, PF>(p, tiles, s); break;
+  }
+}
+
+static int prefetch_depth() {
+  static int pf = [] {
+    const char* e = getenv("FDMI_GEMM_PF");  // experiment knob: 1 = one k-tile of global loads in flight, 2 = two
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
+  return pf;
+}
+
 void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
                        const float* resid, float* C, int M, int N, int K, hipStream_t s) {
   const float a_scale = 16.0f;  // |a| < 4094 stays finite in fp16; lo of |a| > 0.008 is a normal fp16
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
   const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
-  switch (epilogue) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS>), dim3(tiles), dim3(256), 0, s, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_GELU>), dim3(tiles), dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS_RESID>), dim3(tiles), dim3(256), 0, s, p); break;
-  }
+  if (prefetch_depth() == 1) launch_pf<1>(epilogue, p, tiles, s);
+  else launch_pf<2>(epilogue, p, tiles, s);
 }
 
 }  // namespace fdmi

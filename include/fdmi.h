@@ -51,7 +51,8 @@ enum {
   FD_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products + fp32 accumulate */
   FD_PREC_F16X3 = 1 /* GEMM operands split into fp16 hi + lo (22 significant bits), three
                        v_mfma_f32_32x32x16_f16 per product, fp32 accumulate: fp32-class error at
-                       5.3x the fp32-MFMA rate.  Attention / LayerNorm / softmax / GELU stay fp32. */
+                       5.3x the fp32-MFMA rate (GEMMs and the attention contractions).  Softmax,
+                       LayerNorm, GELU, residuals and all accumulation stay fp32. */
 };
 
 typedef struct fd_model fd_model;
@@ -109,7 +110,9 @@ void fd_destroy(fd_model* m);
  *   "fuse_ln"    1: residual + LayerNorm run in the epilogue of the attention-output and
  *                FFN-down GEMMs; 0 (default): separate LayerNorm kernel (same arithmetic).
  *   "use_graph"  1 (default): the per-step kernel sequence is replayed from a hipGraph;
- *                0: eager launches. */
+ *                0: eager launches.
+ *   "attn_f16"   with FD_PREC_F16X3 only -- 1 (default): attention contractions on the fp16x3
+ *                kernel too; 0: keep the exact-fp32 attention kernel. */
 int fd_set_option(fd_model* m, const char* name, int value);
 
 /* ---- parity hooks ---- */

@@ -15,7 +15,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench"
 timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 ${BENCH_ARGS:-} 2>&1 | tail -3 | tee $OUT/bench.log
 if [ -n "${BENCH2_ARGS:-}" ]; then
-  timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline $BENCH2_ARGS 2>&1 | tail -1 | tee $OUT/bench2.log
+  env ${BENCH2_ENV:-X=1} timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline $BENCH2_ARGS 2>&1 | tail -1 | tee $OUT/bench2.log
 fi
 if [ "${WITH_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel-trace --stats (same command as the bench, T=${PROF_T:-200})"
