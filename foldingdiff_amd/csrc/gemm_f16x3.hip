@@ -94,19 +94,21 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging roles: thread t -> A row t/2, 16 floats (k = 16*(t&1) ..); W row t/4, 32 B of its image
+  // Loads are UNCONDITIONAL (row / tile indices are clamped instead of predicated): a load inside
+  // a branch makes hipcc lose count of the outstanding loads and fall back to s_waitcnt vmcnt(2),
+  // which drains the younger prefetch set as well.  Rows >= M therefore accumulate copies of row
+  // M-1; they are never stored.
   const int arow = tid >> 1, au = tid & 1;
-  const bool a_ok = m0 + arow < p.M;
-  const float* aptr = p.A + (size_t)(a_ok ? m0 + arow : 0) * K + 16 * au;
+  const float* aptr = p.A + (size_t)(m0 + arow < p.M ? m0 + arow : p.M - 1) * K + 16 * au;
   const int wrow = tid >> 2, wpart = 2 * (tid & 3);
   const u32x4* wptr = p.Wp + ((size_t)(n0 + wrow) * nk) * 8 + wpart;
 
   float4 ra0[4], ra1[4];
   u32x4 rw0[2], rw1[2];
   auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[2], int kt) {
-    if (kt >= nk) return;
+    kt = kt < nk ? kt : nk - 1;  // past the end: re-load the last tile (never consumed)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      ra[i] = a_ok ? *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i);
     rw[0] = wptr[(size_t)kt * 8];
     rw[1] = wptr[(size_t)kt * 8 + 1];
   };
@@ -161,21 +163,16 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     // even tile kt is in buffer 0; stage odd tile kt+1 into buffer 1 (last read in iteration
-    // kt-1: every wave has passed that barrier)
+    // kt-1: every wave has passed that barrier).  Staging past the last tile is harmless.
     compute(0);
-    if (kt + 1 < nk) {
-      lstore(ra0, rw0, 1);
-      if constexpr (PF == 2) gload(ra0, rw0, kt + 3);
-      else gload(ra1, rw1, kt + 2);
-    }
+    lstore(ra0, rw0, 1);
+    if constexpr (PF == 2) gload(ra0, rw0, kt + 3);
+    else gload(ra1, rw1, kt + 2);
     __syncthreads();
-    if (kt + 1 >= nk) break;
-    compute(1);
-    if (kt + 2 < nk) {
-      lstore(ra1, rw1, 0);
-      if constexpr (PF == 2) gload(ra1, rw1, kt + 4);
-      else gload(ra0, rw0, kt + 3);
-    }
+    if (kt + 1 < nk) compute(1);
+    lstore(ra1, rw1, 0);
+    if constexpr (PF == 2) gload(ra1, rw1, kt + 4);
+    else gload(ra0, rw0, kt + 3);
     __syncthreads();
   }
 

@@ -81,21 +81,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Unconditional loads (indices clamped, not predicated): rows >= M / >= N accumulate copies
+  // of the last valid row and are never stored; a load inside a branch would defeat hipcc's
+  // s_waitcnt vmcnt accounting.
   float4 ra[A_IT], rw[W_IT];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int idx = tid + 256 * i, row = idx / QPR, c4 = idx % QPR;
-      const int gm = m0 + row;
-      ra[i] = gm < p.M ? *reinterpret_cast<const float4*>(p.A + (size_t)gm * K + k0 + c4 * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gm = m0 + row < p.M ? m0 + row : p.M - 1;
+      ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)gm * K + k0 + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int idx = tid + 256 * i, row = idx / QPR, c4 = idx % QPR;
-      const int gn = n0 + row;
-      rw[i] = gn < p.N ? *reinterpret_cast<const float4*>(p.W + (size_t)gn * K + k0 + c4 * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gn = n0 + row < p.N ? n0 + row : p.N - 1;
+      rw[i] = *reinterpret_cast<const float4*>(p.W + (size_t)gn * K + k0 + c4 * 4);
     }
   };
   auto lstore = [&]() {
