@@ -20,7 +20,7 @@
 // overlaps the MFMAs).  Weights are split once at fd_finalize into the LDS row image
 // [n][k/32][hi x32 | lo x32] (128 B).
 //
-// Tiling: 256 x 128 block, 8 waves as 4 x 2, each 64 x 64 (2 x 2 MFMA tiles, 64 accumulator
+// Tiling: (64*WM) x 128 block, WM x 2 waves, each 64 x 64 (2 x 2 MFMA tiles, 64 accumulator
 // registers), BK = 32, LDS double buffered (one barrier per k-tile), and TWO k-tiles of global
 // loads in flight per thread (register prefetch sets): the kernel is L2-latency bound with one.
 // LDS rows are 128 B of payload [hi k0-31 | lo k0-31] padded to 144 B => the 16-byte operand
@@ -70,9 +70,14 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
   lo = __builtin_bit_cast(u32x4, b);
 }
 
-template <int EPI, int PF>
-__global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
-  constexpr int BM = 256, BN = 128, BK = 32, RQ = 9;  // RQ: 16-byte units per padded LDS row (144 B)
+// WM = waves along M: 4 -> 256 x 128 block, 8 waves, one block per CU;
+//                     2 -> 128 x 128 block, 4 waves, two independent blocks per CU (their barrier /
+//                          staging phases overlap each other's MFMA phases).
+template <int EPI, int PF, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
+  constexpr int BM = 64 * WM, BN = 128, BK = 32, RQ = 9;  // RQ: 16-byte units per padded LDS row (144 B)
+  constexpr int NTHR = 128 * WM;
+  constexpr int WU = BN * 8 / NTHR;                       // W image units (16 B) per thread per k-tile
   constexpr int STAGE = (BM + BN) * RQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);  // 2 stages x 55,296 B
@@ -93,26 +98,26 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging roles: thread t -> A row t/2, 16 floats (k = 16*(t&1) ..); W row t/4, 32 B of its image
+  // staging roles: thread t -> A row t/2, 16 floats (k = 16*(t&1) ..); W row t/(8/WU), WU units of its image
   // Loads are UNCONDITIONAL (row / tile indices are clamped instead of predicated): a load inside
   // a branch makes hipcc lose count of the outstanding loads and fall back to s_waitcnt vmcnt(2),
   // which drains the younger prefetch set as well.  Rows >= M therefore accumulate copies of row
   // M-1; they are never stored.
   const int arow = tid >> 1, au = tid & 1;
   const float* aptr = p.A + (size_t)(m0 + arow < p.M ? m0 + arow : p.M - 1) * K + 16 * au;
-  const int wrow = tid >> 2, wpart = 2 * (tid & 3);
+  const int wrow = tid / (8 / WU), wpart = WU * (tid % (8 / WU));
   const u32x4* wptr = p.Wp + ((size_t)(n0 + wrow) * nk) * 8 + wpart;
 
   float4 ra0[4], ra1[4];
-  u32x4 rw0[2], rw1[2];
-  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[2], int kt) {
+  u32x4 rw0[WU], rw1[WU];
+  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[WU], int kt) {
     kt = kt < nk ? kt : nk - 1;  // past the end: re-load the last tile (never consumed)
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i);
-    rw[0] = wptr[(size_t)kt * 8];
-    rw[1] = wptr[(size_t)kt * 8 + 1];
+#pragma unroll
+    for (int i = 0; i < WU; ++i) rw[i] = wptr[(size_t)kt * 8 + i];
   };
-  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[2], int buf) {
+  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[WU], int buf) {
     u32x4* S = smem + buf * STAGE;
     u32x4 h0, l0, h1, l1;
     split8(ra[0], ra[1], p.a_scale, h0, l0);
@@ -120,8 +125,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
     u32x4* row = S + arow * RQ;  // [hi k0-31 (4 units) | lo k0-31 (4 units) | pad]
     row[2 * au] = h0; row[2 * au + 1] = h1; row[4 + 2 * au] = l0; row[4 + 2 * au + 1] = l1;
     u32x4* wr = S + (BM + wrow) * RQ + wpart;
-    wr[0] = rw[0];
-    wr[1] = rw[1];
+#pragma unroll
+    for (int i = 0; i < WU; ++i) wr[i] = rw[i];
   };
   auto compute = [&](int buf) {
     const u32x4* S = smem + buf * STAGE;
@@ -198,43 +203,49 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(GemmSplitArgs p) {
     }
 }
 
-constexpr int kSplitSmem = 2 * (256 + 128) * 9 * 16;  // 110,592 B
-
-template <int EPI, int PF>
-static void launch_one(const GemmSplitArgs& p, int tiles, hipStream_t s) {
+template <int EPI, int PF, int WM>
+static void launch_one(const GemmSplitArgs& p, hipStream_t s) {
+  constexpr int BM = 64 * WM;
+  constexpr int smem = 2 * (BM + 128) * 9 * 16;  // WM=4: 110,592 B; WM=2: 73,728 B
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<EPI, PF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kSplitSmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<EPI, PF, WM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, PF>), dim3(tiles), dim3(512), kSplitSmem, s, p);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
+  hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, PF, WM>), dim3(tiles), dim3(128 * WM), smem, s, p);
 }
 
-template <int PF>
-static void launch_pf(int epilogue, const GemmSplitArgs& p, int tiles, hipStream_t s) {
+template <int PF, int WM>
+static void launch_pf(int epilogue, const GemmSplitArgs& p, hipStream_t s) {
   switch (epilogue) {
-    case EPI_BIAS: launch_one<EPI_BIAS, PF>(p, tiles, s); break;
-    case EPI_BIAS_GELU: launch_one<EPI_BIAS_GELU, PF>(p, tiles, s); break;
-    default: launch_one<EPI_BIAS_RESID, PF>(p, tiles, s); break;
+    case EPI_BIAS: launch_one<EPI_BIAS, PF, WM>(p, s); break;
+    case EPI_BIAS_GELU: launch_one<EPI_BIAS_GELU, PF, WM>(p, s); break;
+    default: launch_one<EPI_BIAS_RESID, PF, WM>(p, s); break;
   }
 }
 
-static int prefetch_depth() {
-  static int pf = [] {
-    const char* e = getenv("FDMI_GEMM_PF");  // experiment knob: 1 = one k-tile of global loads in flight, 2 = two
-    return (e && e[0] == '1') ? 1 : 2;
-  }();
-  return pf;
+// experiment knobs (environment, read once): FDMI_GEMM_PF = 1|2 k-tiles of global loads in flight,
+// FDMI_GEMM_BM = 128|256 rows per workgroup
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
                        const float* resid, float* C, int M, int N, int K, hipStream_t s) {
+  static const int pf = env_int("FDMI_GEMM_PF", 2) == 1 ? 1 : 2;
+  static const int bm = env_int("FDMI_GEMM_BM", 128) == 256 ? 256 : 128;
   const float a_scale = 16.0f;  // |a| < 4094 stays finite in fp16; lo of |a| > 0.008 is a normal fp16
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
-  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
-  if (prefetch_depth() == 1) launch_pf<1>(epilogue, p, tiles, s);
-  else launch_pf<2>(epilogue, p, tiles, s);
+  if (bm == 256) {
+    if (pf == 1) launch_pf<1, 4>(epilogue, p, s);
+    else launch_pf<2, 4>(epilogue, p, s);
+  } else {
+    if (pf == 1) launch_pf<1, 2>(epilogue, p, s);
+    else launch_pf<2, 2>(epilogue, p, s);
+  }
 }
 
 }  // namespace fdmi

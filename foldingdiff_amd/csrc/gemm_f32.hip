@@ -84,31 +84,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   // Unconditional loads (indices clamped, not predicated): rows >= M / >= N accumulate copies
   // of the last valid row and are never stored; a load inside a branch would defeat hipcc's
   // s_waitcnt vmcnt accounting.
-  float4 ra[A_IT], rw[W_IT];
+  f32x4 ra[A_IT], rw[W_IT];  // ext_vector registers (HIP's float4 struct copies can end up in scratch)
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int idx = tid + 256 * i, row = idx / QPR, c4 = idx % QPR;
       const int gm = m0 + row < p.M ? m0 + row : p.M - 1;
-      ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)gm * K + k0 + c4 * 4);
+      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gm * K + k0 + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int idx = tid + 256 * i, row = idx / QPR, c4 = idx % QPR;
       const int gn = n0 + row < p.N ? n0 + row : p.N - 1;
-      rw[i] = *reinterpret_cast<const float4*>(p.W + (size_t)gn * K + k0 + c4 * 4);
+      rw[i] = *reinterpret_cast<const f32x4*>(p.W + (size_t)gn * K + k0 + c4 * 4);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int idx = tid + 256 * i, row = idx / QPR, c4 = idx % QPR;
-      *reinterpret_cast<float4*>(&As[row * LDK + c4 * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&As[row * LDK + c4 * 4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int idx = tid + 256 * i, row = idx / QPR, c4 = idx % QPR;
-      *reinterpret_cast<float4*>(&Ws[row * LDK + c4 * 4]) = rw[i];
+      *reinterpret_cast<f32x4*>(&Ws[row * LDK + c4 * 4]) = rw[i];
     }
   };
 

@@ -17,6 +17,9 @@ timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 ${BENCH_ARGS:-}
 if [ -n "${BENCH2_ARGS:-}" ]; then
   env ${BENCH2_ENV:-X=1} timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline $BENCH2_ARGS 2>&1 | tail -1 | tee $OUT/bench2.log
 fi
+if [ -n "${BENCH3_ARGS:-}" ]; then
+  env ${BENCH3_ENV:-X=1} timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline $BENCH3_ARGS 2>&1 | tail -1 | tee $OUT/bench3.log
+fi
 if [ "${WITH_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel-trace --stats (same command as the bench, T=${PROF_T:-200})"
   R=$PWD
@@ -33,5 +36,18 @@ if [ "${WITH_PROF:-1}" = "1" ]; then
   cat $OUT/prof_summary.txt | cut -c1-200
   find $OUT -name "*kernel_trace.csv" -size +8M -delete
   find $OUT -name "*.db" -delete
+fi
+if [ -n "${PMC_EXTRA:-}" ]; then
+  R=$PWD; cd /tmp; i=0
+  IFS=';' read -ra SETS <<< "$PMC_EXTRA"
+  for set in "${SETS[@]}"; do
+    i=$((i+1)); echo "== rocprofv3 --pmc $set"
+    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pmcx_$i -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 3 --profile-every 0 --no-cpu-baseline ${BENCH_ARGS:-} > $R/$OUT/pmcx_$i.log 2>&1
+    tail -1 $R/$OUT/pmcx_$i.log | cut -c1-160
+  done
+  cd $R
+  python scripts/pmc_summary.py $OUT > $OUT/prof_summary.txt 2>&1
+  grep -E "gemm|attn" $OUT/prof_summary.txt | grep -v "^#" | cut -c1-170
+  find $OUT -name "*kernel_trace.csv" -size +8M -delete
 fi
 echo "== done"
