@@ -348,7 +348,7 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
     PROF(KC_ATTN, ok = (m->precision == FD_PREC_F16X3 && m->attn_f16)
                         ? launch_attention_f16x3(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s)
                         : launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
-    if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by this build (max 128)", L);
+    if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by the fp32 kernel (max 128)", L);
     bool fused = false;
     if (fuse_ln)
       PROF(KC_GEMM_OUT, fused = launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
@@ -440,7 +440,8 @@ int check_shape(fd_model* m, int B, int L, int t) {
     return fail(FD_E_INVALID, "L=%d exceeds max_position_embeddings=%d", L, m->cfg.max_pos);
   if (m->cfg.pos_type == FD_POS_ABSOLUTE && L > m->cfg.max_pos)
     return fail(FD_E_INVALID, "L=%d exceeds max_position_embeddings=%d", L, m->cfg.max_pos);
-  if (L > 128) return fail(FD_E_UNSUPPORTED, "L=%d: this build tiles attention for L <= 128", L);
+  if (L > 128 && !(m->precision == FD_PREC_F16X3 && m->attn_f16))
+    return fail(FD_E_UNSUPPORTED, "L=%d: the exact-fp32 attention kernel handles L <= 128; use FD_PREC_F16X3", L);
   return FD_OK;
 }
 

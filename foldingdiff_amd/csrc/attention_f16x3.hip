@@ -4,7 +4,9 @@
 // x*s = hi + lo (fp16 each, s a power of two) and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is
 // issued as three v_mfma_f32_32x32x16_f16 into one fp32 accumulator (see gemm_f16x3.hip).
 //
-// One 8-wave workgroup per (sequence, pair of heads); a wave owns 32-query row blocks.
+// One 8-wave workgroup per (sequence, pair of heads, group of 128 queries); a wave owns one 32-query
+// row block and walks the key tiles (128 keys each) with a flash-style online softmax, so any
+// L <= max_position_embeddings fits (L <= 128: a single tile).
 //   LDS (fp16 hi|lo row images, rows padded so the 16/8-byte operand fetches are conflict free):
 //     K   [2 heads][LP keys][hi d0-31 | lo d0-31]      144 B rows
 //     E   [2*LP band rows][hi | lo]                     144 B rows   (relative_key only; shared by both heads)
@@ -19,7 +21,8 @@
 //     S^T[r, l] += R[l, l - r + c] transposes queries from registers to lanes, so R goes through
 //     the wave's LDS scratch one 32x32 tile at a time and is read back with per-lane addresses
 //     (row l = lane, column l - r + const: bank = 5*lane mod 32, conflict free).
-//   * O = P . V : A = P (registers, split to fp16 hi/lo after the softmax), B = Vt (LDS).
+//   * O^T = V^T . P^T : A = Vt (LDS), B = P (registers, split to fp16 hi/lo after the softmax).  In the
+//     transposed form queries stay in lanes, so the online-softmax rescale is a per-lane scalar.
 // Scores, probabilities and the context accumulate in fp32; nothing but q|k|v and ctx touches HBM.
 #include "fdmi_kernels.h"
 
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
                                                                const float* __restrict__ demb,
                                                                const int* __restrict__ lens, float* __restrict__ ctx,
                                                                int L, int H, int maxpos) {
-  constexpr int LP = 32 * T;
+  constexpr int LP = 32 * T;        // keys per key tile = queries per query group
   constexpr int NT = 256 * HPB;
   constexpr int VROW = 4 * LP + 8;  // bytes per Vt row: LP hi + LP lo halves + 8 B pad (b64 reads conflict free)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
@@ -86,94 +89,111 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int hgroups = (H + HPB - 1) / HPB;
-  const int b = blockIdx.x / hgroups, h0 = (blockIdx.x % hgroups) * HPB;
+  const int nqg = (L + LP - 1) / LP;  // query groups == key tiles (1 when L <= 128)
+  const int qg = blockIdx.x % nqg;
+  const int b = (blockIdx.x / nqg) / hgroups, h0 = ((blockIdx.x / nqg) % hgroups) * HPB;
   const int d = H * 32, ld = 3 * d;
   const int len = lens[b];
   const float* seq = qkv + (size_t)b * L * ld;
 
-  // ---- fill K (row images) : one thread per (head, key, 8-wide d octet)
-  for (int idx = tid; idx < HPB * LP * 4; idx += NT) {
-    const int hh = idx / (LP * 4), rem = idx % (LP * 4);
-    const int r = rem >> 2, oct = rem & 3;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
-    if (r < L && h0 + hh < H) {
-      const float* src = seq + (size_t)r * ld + d + (h0 + hh) * 32 + oct * 8;
-      p = *reinterpret_cast<const float4*>(src);
-      q = *reinterpret_cast<const float4*>(src + 4);
-    }
-    f16x8 hi, lo;
-    split8(p, q, KS, hi, lo);
-    unsigned char* row = Ks + (size_t)(hh * LP + r) * KROW;
-    *reinterpret_cast<u32x4*>(row + oct * 16) = __builtin_bit_cast(u32x4, hi);
-    *reinterpret_cast<u32x4*>(row + 64 + oct * 16) = __builtin_bit_cast(u32x4, lo);
-  }
-  // ---- fill Vt (transposed): one thread per (head, key pair, 4-wide d group)
-  for (int idx = tid; idx < HPB * (LP / 2) * 8; idx += NT) {
-    const int hh = idx / ((LP / 2) * 8), rem = idx % ((LP / 2) * 8);
-    const int kp = rem >> 3, c4 = rem & 7;
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    if (h0 + hh < H) {
-      const float* src = seq + 2 * d + (h0 + hh) * 32 + c4 * 4;
-      if (2 * kp < L) v0 = *reinterpret_cast<const float4*>(src + (size_t)(2 * kp) * ld);
-      if (2 * kp + 1 < L) v1 = *reinterpret_cast<const float4*>(src + (size_t)(2 * kp + 1) * ld);
-    }
-    const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+  const int hh = wid >> 2, wq = wid & 3, h = h0 + hh;
+  const int l0 = qg * LP + 32 * wq;                       // first query of this wave's row block
+  const bool active = h < H && wq < T && l0 < L;          // inactive waves only help filling LDS
+  const float* base = seq + (h < H ? h : 0) * 32;
+  const unsigned char* Kh = Ks + (size_t)hh * LP * KROW;
+  const unsigned char* Vh = Vt + (size_t)hh * 32 * VROW;
+  float* Rw = Rs + wid * 32 * RLD;
+
+  // Q operand: lane (query l31, half) holds d = 16c + 8*half + j   (B of K.Q^T and A of Q.E^T alike)
+  f16x8 qh[2], ql[2];
+  {
+    const int l = l0 + l31;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f16x2 hi, lo;
-      _Float16 h, l;
-      split1(a0[i], VS, h, l); hi[0] = h; lo[0] = l;
-      split1(a1[i], VS, h, l); hi[1] = h; lo[1] = l;
-      unsigned char* row = Vt + (size_t)(hh * 32 + c4 * 4 + i) * VROW;
-      *reinterpret_cast<unsigned*>(row + 4 * kp) = __builtin_bit_cast(unsigned, hi);
-      *reinterpret_cast<unsigned*>(row + 2 * LP + 4 * kp) = __builtin_bit_cast(unsigned, lo);
+    for (int c = 0; c < 2; ++c) {
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+      if (active && l < L) {
+        const float* src = base + (size_t)l * ld + 16 * c + 8 * half;
+        p = *reinterpret_cast<const float4*>(src);
+        q = *reinterpret_cast<const float4*>(src + 4);
+      }
+      split8(p, q, QS, qh[c], ql[c]);
     }
   }
-  if constexpr (REL) {
-    // Es[e] = E[m_min + e], m_min = (maxpos-1) - (LP-1); rows outside the table are zero
-    const int m_min = (maxpos - 1) - (LP - 1);
-    for (int idx = tid; idx < 2 * LP * 4; idx += NT) {
-      const int e = idx >> 2, oct = idx & 3, m = e + m_min;
+  // running softmax state of this lane's query (identical in both half-waves) and O^T accumulator:
+  // rows = d (C/D row map), cols = queries (lanes) -> the per-query rescale is a per-lane scalar
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+
+  for (int kt = 0; kt < nqg; ++kt) {
+    const int r0 = kt * LP;  // first key of the tile
+    // keys >= len carry the additive -10000 and underflow to exactly 0 after the softmax (there is
+    // always an unmasked key in tile 0), so tiles made only of such keys are skipped
+    if (r0 >= len) break;
+    if (kt > 0) __syncthreads();  // everyone is done reading the previous tile
+    // ---- fill K (row images) : one thread per (head, key, 8-wide d octet)
+    for (int idx = tid; idx < HPB * LP * 4; idx += NT) {
+      const int fh = idx / (LP * 4), rem = idx % (LP * 4);
+      const int r = rem >> 2, oct = rem & 3;
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
-      if (m >= 0 && m <= 2 * (maxpos - 1)) {
-        const float* src = demb + (size_t)m * 32 + oct * 8;
+      if (r0 + r < L && h0 + fh < H) {
+        const float* src = seq + (size_t)(r0 + r) * ld + d + (h0 + fh) * 32 + oct * 8;
         p = *reinterpret_cast<const float4*>(src);
         q = *reinterpret_cast<const float4*>(src + 4);
       }
       f16x8 hi, lo;
-      split8(p, q, ES, hi, lo);
-      unsigned char* row = Es + (size_t)e * KROW;
+      split8(p, q, KS, hi, lo);
+      unsigned char* row = Ks + (size_t)(fh * LP + r) * KROW;
       *reinterpret_cast<u32x4*>(row + oct * 16) = __builtin_bit_cast(u32x4, hi);
       *reinterpret_cast<u32x4*>(row + 64 + oct * 16) = __builtin_bit_cast(u32x4, lo);
     }
-  }
-  __syncthreads();
-
-  const int hh = wid >> 2, wq = wid & 3, h = h0 + hh;
-  if (h >= H) return;
-  const float* base = seq + h * 32;
-  const unsigned char* Kh = Ks + (size_t)hh * LP * KROW;
-  const unsigned char* Vh = Vt + (size_t)hh * 32 * VROW;
-  float* Rw = Rs + wid * 32 * RLD;
-  const int nrb = (L + 31) >> 5;
-  for (int rb = wq; rb < nrb; rb += 4) {
-    const int l0 = rb * 32;
-    // Q operand: lane (query l31, half) holds d = 16c + 8*half + j   (B of K.Q^T and A of Q.E^T alike)
-    f16x8 qh[2], ql[2];
-    {
-      const int l = l0 + l31;
+    // ---- fill Vt (transposed): one thread per (head, key pair, 4-wide d group)
+    for (int idx = tid; idx < HPB * (LP / 2) * 8; idx += NT) {
+      const int fh = idx / ((LP / 2) * 8), rem = idx % ((LP / 2) * 8);
+      const int kp = rem >> 3, c4 = rem & 7;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (h0 + fh < H) {
+        const float* src = seq + 2 * d + (h0 + fh) * 32 + c4 * 4;
+        if (r0 + 2 * kp < L) v0 = *reinterpret_cast<const float4*>(src + (size_t)(r0 + 2 * kp) * ld);
+        if (r0 + 2 * kp + 1 < L) v1 = *reinterpret_cast<const float4*>(src + (size_t)(r0 + 2 * kp + 1) * ld);
+      }
+      const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int i = 0; i < 4; ++i) {
+        f16x2 hi, lo;
+        _Float16 hv, lv;
+        split1(a0[i], VS, hv, lv); hi[0] = hv; lo[0] = lv;
+        split1(a1[i], VS, hv, lv); hi[1] = hv; lo[1] = lv;
+        unsigned char* row = Vt + (size_t)(fh * 32 + c4 * 4 + i) * VROW;
+        *reinterpret_cast<unsigned*>(row + 4 * kp) = __builtin_bit_cast(unsigned, hi);
+        *reinterpret_cast<unsigned*>(row + 2 * LP + 4 * kp) = __builtin_bit_cast(unsigned, lo);
+      }
+    }
+    if constexpr (REL) {
+      // Es[e] = E[m_min + e]; for group-relative l', r' in [0, LP): m = l' - r' + (maxpos-1) + LP*(qg-kt),
+      // so m_min = (maxpos-1) - (LP-1) + LP*(qg-kt); rows outside the table are zero (never selected
+      // for a valid (l, r) pair because L <= max_position_embeddings)
+      const int m_min = (maxpos - 1) - (LP - 1) + LP * (qg - kt);
+      for (int idx = tid; idx < 2 * LP * 4; idx += NT) {
+        const int e = idx >> 2, oct = idx & 3, m = e + m_min;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
-        if (l < L) {
-          const float* src = base + (size_t)l * ld + 16 * c + 8 * half;
+        if (m >= 0 && m <= 2 * (maxpos - 1)) {
+          const float* src = demb + (size_t)m * 32 + oct * 8;
           p = *reinterpret_cast<const float4*>(src);
           q = *reinterpret_cast<const float4*>(src + 4);
         }
-        split8(p, q, QS, qh[c], ql[c]);
+        f16x8 hi, lo;
+        split8(p, q, ES, hi, lo);
+        unsigned char* row = Es + (size_t)e * KROW;
+        *reinterpret_cast<u32x4*>(row + oct * 16) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(row + 64 + oct * 16) = __builtin_bit_cast(u32x4, lo);
       }
     }
-    // S^T tiles: rows = keys 32t + rowmap(r, half), cols = queries l0 + l31
+    __syncthreads();
+    if (!active) continue;
+
+    // S^T tiles: rows = keys r0 + 32t + rowmap(r, half), cols = queries l0 + l31
     f32x16 sacc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -195,16 +215,17 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[t][r] *= S_SCALE;
     if constexpr (REL) {
-      // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31, i.e.
-      // m = m_min + l0 + 32q + l31.  S^T tile t element (key kl, query ql) needs band column
-      // j = ql - kl + 31 of the tile pair (q = T-1-t, q+1):  j < 32 -> tile q, else tile q+1 col j-32.
+      // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31 (band origin: this
+      // wave's row block, i.e. Es row 32*wq + 32q + l31).  S^T tile t element (key kl, query ql)
+      // needs band column j = ql - kl + 31 of the tile pair (q = T-1-t, q+1):  j < 32 -> tile q,
+      // else tile q+1 column j-32.
       constexpr float R_SCALE = 1.0f / (QS * ES);
 #pragma unroll
       for (int q = 0; q <= T; ++q) {
         f32x16 racc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-        const unsigned char* row = Es + (size_t)(l0 + 32 * q + l31) * KROW;
+        const unsigned char* row = Es + (size_t)(32 * wq + 32 * q + l31) * KROW;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const f16x8 eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 32 * c + 16 * half));
@@ -243,35 +264,39 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
         __builtin_amdgcn_wave_barrier();
       }
     }
-    // scale, mask, softmax over keys: this lane + its partner (lane ^ 32) hold one query's scores
-    float mx = -INFINITY;
+    // scale, mask, online softmax over keys: this lane + its partner (lane ^ 32) hold one query's scores
+    float mt = -INFINITY;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float s = sacc[t][r] * 0.17677669529663687f;  // / sqrt(attention_head_size = 32)
-        if (key >= len) s += -10000.0f;               // (1 - mask) * -10000   (modelling.py:452)
-        if (key >= L) s = -INFINITY;                  // tile padding: not a key at all
-        sacc[t][r] = s;
-        mx = fmaxf(mx, s);
+        const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float sc = sacc[t][r] * 0.17677669529663687f;  // / sqrt(attention_head_size = 32)
+        if (key >= len) sc += -10000.0f;               // (1 - mask) * -10000   (modelling.py:452)
+        if (key >= L) sc = -INFINITY;                  // tile padding: not a key at all
+        sacc[t][r] = sc;
+        mt = fmaxf(mt, sc);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp_neg(m_run - m_new);  // first tile: exp(-inf) -> 0 (accumulators are 0 anyway)
+    float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pexp = exp_neg(sacc[t][r] - mx);
+        const float pexp = exp_neg(sacc[t][r] - m_new);
         sacc[t][r] = pexp;
-        sum += pexp;
+        psum += pexp;
       }
-    sum += __shfl_xor(sum, 32);
-    const float inv = PS / sum;  // probabilities carried scaled by PS into the fp16 split
-    // O = P V:  A[i = query l31][position (c, half, j)] = P[key 32t + 16c + 8(j>>2) + 4half + (j&3)] = sacc[t][8c + j]
-    f32x16 oacc;
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],
+    //                   B[position][n = query l31] = P[query][key(c,half,j)] = sacc[t][8c + j],
+    //                   key(c, half, j) = 32t + 16c + 8(j>>2) + 4*half + (j&3)   (the C/D row map)
     const unsigned char* vrow = Vh + (size_t)l31 * VROW;
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
         f16x8 ph, pl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xs = sacc[t][8 * c + j] * inv;
+          const float xs = sacc[t][8 * c + j] * PS;  // unnormalised probabilities (<= 1), scaled for the fp16 split
           const _Float16 hv = (_Float16)xs;
           ph[j] = hv;
           pl[j] = (_Float16)(xs - (float)hv);
@@ -294,16 +319,22 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
         const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
         const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
         const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, oacc, 0, 0, 0);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oacc, 0, 0, 0);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc, 0, 0, 0);
       }
-    constexpr float O_SCALE = 1.0f / (PS * VS);
+  }
+  if (!active) return;
+  // ctx[query][h*32 + d] = O^T[d][query] / l_run : this lane owns query l0 + l31 and, per register
+  // quad, four consecutive d = 8*(r>>2) + 4*half + (r&3)
+  const int l = l0 + l31;
+  if (l < L) {
+    const float onorm = 1.0f / (PS * VS * l_run);
+    float* dst = ctx + ((size_t)b * L + l) * d + h * 32 + 4 * half;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int l = l0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (l < L) ctx[((size_t)b * L + l) * d + h * 32 + l31] = oacc[r] * O_SCALE;
-    }
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(dst + 8 * g) =
+          make_float4(oacc[4 * g] * onorm, oacc[4 * g + 1] * onorm, oacc[4 * g + 2] * onorm, oacc[4 * g + 3] * onorm);
   }
 }
 
@@ -320,16 +351,17 @@ static void launch_t(const float* qkv, const float* demb, const int* lens, float
     attr_set = true;
   }
   const int hgroups = (H + HPB - 1) / HPB;
-  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL>), dim3(B * hgroups), dim3(256 * HPB), smem, s, qkv, demb, lens, ctx, L,
-                     H, maxpos);
+  const int nqg = (L + LP - 1) / LP;
+  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv, demb, lens,
+                     ctx, L, H, maxpos);
 }
 
 }  // namespace a16
 
 bool launch_attention_f16x3(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
                             int maxpos, hipStream_t s) {
-  if (L < 1 || L > 128) return false;
-  const int T = (L + 31) / 32;
+  if (L < 1) return false;
+  const int T = L > 128 ? 4 : (L + 31) / 32;  // long sequences: 128-key tiles x 128-query groups, online softmax
   const bool rel = dist_emb != nullptr;
 #define FD_ATTN16_CASE(TT)                                                             \
   case TT:                                                                             \

@@ -73,7 +73,10 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
 // WM = waves along M: 4 -> 256 x 128 block, 8 waves, one block per CU;
 //                     2 -> 128 x 128 block, 4 waves, two independent blocks per CU (their barrier /
 //                          staging phases overlap each other's MFMA phases).
-template <int EPI, int PF, int WM>
+// AL = A-staging layout: 0 -> thread = (row, 64-byte half of the 128-byte k-tile row), four dwordx4 loads
+//                        1 -> thread = two (row, 32-byte octet) pairs: 4 consecutive lanes cover one full
+//                             128-byte line with two dwordx4 loads (half the cache-line requests per instruction)
+template <int EPI, int PF, int WM, int AL>
 __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
   constexpr int BM = 64 * WM, BN = 128, BK = 32, RQ = 9;  // RQ: 16-byte units per padded LDS row (144 B)
   constexpr int NTHR = 128 * WM;
@@ -103,8 +106,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
   // a branch makes hipcc lose count of the outstanding loads and fall back to s_waitcnt vmcnt(2),
   // which drains the younger prefetch set as well.  Rows >= M therefore accumulate copies of row
   // M-1; they are never stored.
-  const int arow = tid >> 1, au = tid & 1;
-  const float* aptr = p.A + (size_t)(m0 + arow < p.M ? m0 + arow : p.M - 1) * K + 16 * au;
+  const int arow = AL == 0 ? tid >> 1 : tid >> 2, au = AL == 0 ? tid & 1 : tid & 3;
+  const int arow2 = arow + NTHR / 4;  // AL == 1: second (row, octet) pair of this thread
+  const float* aptr = p.A + (size_t)(m0 + arow < p.M ? m0 + arow : p.M - 1) * K + (AL == 0 ? 16 : 8) * au;
+  const float* aptr2 = p.A + (size_t)(m0 + arow2 < p.M ? m0 + arow2 : p.M - 1) * K + 8 * au;
   const int wrow = tid / (8 / WU), wpart = WU * (tid % (8 / WU));
   const u32x4* wptr = p.Wp + ((size_t)(n0 + wrow) * nk) * 8 + wpart;
 
@@ -112,8 +117,15 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
   u32x4 rw0[WU], rw1[WU];
   auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[WU], int kt) {
     kt = kt < nk ? kt : nk - 1;  // past the end: re-load the last tile (never consumed)
+    if constexpr (AL == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i);
+      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(aptr + kt * BK + 4 * i);
+    } else {
+      ra[0] = *reinterpret_cast<const float4*>(aptr + kt * BK);
+      ra[1] = *reinterpret_cast<const float4*>(aptr + kt * BK + 4);
+      ra[2] = *reinterpret_cast<const float4*>(aptr2 + kt * BK);
+      ra[3] = *reinterpret_cast<const float4*>(aptr2 + kt * BK + 4);
+    }
 #pragma unroll
     for (int i = 0; i < WU; ++i) rw[i] = wptr[(size_t)kt * 8 + i];
   };
@@ -123,7 +135,12 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
     split8(ra[0], ra[1], p.a_scale, h0, l0);
     split8(ra[2], ra[3], p.a_scale, h1, l1);
     u32x4* row = S + arow * RQ;  // [hi k0-31 (4 units) | lo k0-31 (4 units) | pad]
-    row[2 * au] = h0; row[2 * au + 1] = h1; row[4 + 2 * au] = l0; row[4 + 2 * au + 1] = l1;
+    if constexpr (AL == 0) {
+      row[2 * au] = h0; row[2 * au + 1] = h1; row[4 + 2 * au] = l0; row[4 + 2 * au + 1] = l1;
+    } else {
+      u32x4* rowb = S + arow2 * RQ;
+      row[au] = h0; row[4 + au] = l0; rowb[au] = h1; rowb[4 + au] = l1;
+    }
     u32x4* wr = S + (BM + wrow) * RQ + wpart;
 #pragma unroll
     for (int i = 0; i < WU; ++i) wr[i] = rw[i];
@@ -203,31 +220,31 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
     }
 }
 
-template <int EPI, int PF, int WM>
+template <int EPI, int PF, int WM, int AL>
 static void launch_one(const GemmSplitArgs& p, hipStream_t s) {
   constexpr int BM = 64 * WM;
   constexpr int smem = 2 * (BM + 128) * 9 * 16;  // WM=4: 110,592 B; WM=2: 73,728 B
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<EPI, PF, WM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<EPI, PF, WM, AL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
-  hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, PF, WM>), dim3(tiles), dim3(128 * WM), smem, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, PF, WM, AL>), dim3(tiles), dim3(128 * WM), smem, s, p);
 }
 
-template <int PF, int WM>
+template <int WM, int AL>
 static void launch_pf(int epilogue, const GemmSplitArgs& p, hipStream_t s) {
   switch (epilogue) {
-    case EPI_BIAS: launch_one<EPI_BIAS, PF, WM>(p, s); break;
-    case EPI_BIAS_GELU: launch_one<EPI_BIAS_GELU, PF, WM>(p, s); break;
-    default: launch_one<EPI_BIAS_RESID, PF, WM>(p, s); break;
+    case EPI_BIAS: launch_one<EPI_BIAS, 2, WM, AL>(p, s); break;
+    case EPI_BIAS_GELU: launch_one<EPI_BIAS_GELU, 2, WM, AL>(p, s); break;
+    default: launch_one<EPI_BIAS_RESID, 2, WM, AL>(p, s); break;
   }
 }
 
-// experiment knobs (environment, read once): FDMI_GEMM_PF = 1|2 k-tiles of global loads in flight,
-// FDMI_GEMM_BM = 128|256 rows per workgroup
+// experiment knobs (environment, read once): FDMI_GEMM_BM = 128|256 rows per workgroup,
+// FDMI_GEMM_AL = 0|1 A-staging layout
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -235,16 +252,16 @@ static int env_int(const char* name, int dflt) {
 
 void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
                        const float* resid, float* C, int M, int N, int K, hipStream_t s) {
-  static const int pf = env_int("FDMI_GEMM_PF", 2) == 1 ? 1 : 2;
-  static const int bm = env_int("FDMI_GEMM_BM", 128) == 256 ? 256 : 128;
+  static const int al = env_int("FDMI_GEMM_AL", 1) == 0 ? 0 : 1;
+  static const int bm = env_int("FDMI_GEMM_BM", 256) == 128 ? 128 : 256;
   const float a_scale = 16.0f;  // |a| < 4094 stays finite in fp16; lo of |a| > 0.008 is a normal fp16
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
   if (bm == 256) {
-    if (pf == 1) launch_pf<1, 4>(epilogue, p, s);
-    else launch_pf<2, 4>(epilogue, p, s);
+    if (al == 0) launch_pf<4, 0>(epilogue, p, s);
+    else launch_pf<4, 1>(epilogue, p, s);
   } else {
-    if (pf == 1) launch_pf<1, 2>(epilogue, p, s);
-    else launch_pf<2, 2>(epilogue, p, s);
+    if (al == 0) launch_pf<2, 0>(epilogue, p, s);
+    else launch_pf<2, 1>(epilogue, p, s);
   }
 }
 
