@@ -869,6 +869,65 @@ int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, con
   return rc;
 }
 
+int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int reps, double* ms_per_launch) {
+  if (!ms_per_launch || M < 1 || N < 1 || K < 32 || K % 32 || reps < 1) return fail(FD_E_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(device_id));
+  std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N, 0.1f);
+  unsigned st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+  for (auto& v : hA) v = rnd();
+  for (auto& v : hW) v = 0.02f * rnd();
+  float *dA = nullptr, *dW = nullptr, *db = nullptr, *dC = nullptr;
+  void* dWp = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)dA, (void*)dW, (void*)db, (void*)dC, dWp})
+      if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  };
+#define T_TRY(expr)                                                          \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      cleanup();                                                             \
+      return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    }                                                                        \
+  } while (0)
+  T_TRY(hipMalloc((void**)&dA, hA.size() * 4));
+  T_TRY(hipMalloc((void**)&dW, hW.size() * 4));
+  T_TRY(hipMalloc((void**)&db, (size_t)N * 4));
+  T_TRY(hipMalloc((void**)&dC, (size_t)M * N * 4));
+  T_TRY(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  T_TRY(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  T_TRY(hipMemcpy(db, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+  float wscale = 1.f;
+  if (precision == FD_PREC_F16X3) {
+    std::vector<uint16_t> img;
+    pack_split_weight(hW.data(), N, K, &img, &wscale);
+    T_TRY(hipMalloc(&dWp, img.size() * 2));
+    T_TRY(hipMemcpy(dWp, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  }
+  T_TRY(hipEventCreate(&e0));
+  T_TRY(hipEventCreate(&e1));
+  auto run = [&]() {
+    if (precision == FD_PREC_F16X3) launch_gemm_f16x3(EPI_BIAS, dA, dWp, wscale, db, nullptr, dC, M, N, K, nullptr);
+    else launch_gemm_f32(EPI_BIAS, dA, dW, db, nullptr, dC, M, N, K, nullptr);
+  };
+  for (int i = 0; i < 3; ++i) run();
+  T_TRY(hipDeviceSynchronize());
+  T_TRY(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < reps; ++i) run();
+  T_TRY(hipEventRecord(e1, nullptr));
+  T_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  T_TRY(hipEventElapsedTime(&ms, e0, e1));
+#undef T_TRY
+  *ms_per_launch = ms / reps;
+  cleanup();
+  return FD_OK;
+}
+
 int fd_profile_every(fd_model* m, int n) {
   if (!m || n < 0) return fail(FD_E_INVALID, "bad argument");
   m->profile_every = n;

@@ -76,7 +76,10 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
 // AL = A-staging layout: 0 -> thread = (row, 64-byte half of the 128-byte k-tile row), four dwordx4 loads
 //                        1 -> thread = two (row, 32-byte octet) pairs: 4 consecutive lanes cover one full
 //                             128-byte line with two dwordx4 loads (half the cache-line requests per instruction)
-template <int EPI, int PF, int WM, int AL>
+// DBG (ablation builds, never used by the product path; results are wrong by design):
+//   1 = no MFMAs (operands still fetched from LDS), 2 = no global loads / LDS staging inside the
+//   k-loop, 3 = staging without the fp32 -> hi/lo conversion.
+template <int EPI, int PF, int WM, int AL, int DBG = 0>
 __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
   constexpr int BM = 64 * WM, BN = 128, BK = 32, RQ = 9;  // RQ: 16-byte units per padded LDS row (144 B)
   constexpr int NTHR = 128 * WM;
@@ -132,8 +135,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
   auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[WU], int buf) {
     u32x4* S = smem + buf * STAGE;
     u32x4 h0, l0, h1, l1;
-    split8(ra[0], ra[1], p.a_scale, h0, l0);
-    split8(ra[2], ra[3], p.a_scale, h1, l1);
+    if constexpr (DBG == 3) {
+      h0 = __builtin_bit_cast(u32x4, ra[0]); l0 = __builtin_bit_cast(u32x4, ra[1]);
+      h1 = __builtin_bit_cast(u32x4, ra[2]); l1 = __builtin_bit_cast(u32x4, ra[3]);
+    } else {
+      split8(ra[0], ra[1], p.a_scale, h0, l0);
+      split8(ra[2], ra[3], p.a_scale, h1, l1);
+    }
     u32x4* row = S + arow * RQ;  // [hi k0-31 (4 units) | lo k0-31 (4 units) | pad]
     if constexpr (AL == 0) {
       row[2 * au] = h0; row[2 * au + 1] = h1; row[4 + 2 * au] = l0; row[4 + 2 * au + 1] = l1;
@@ -162,6 +170,11 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
         bh[j] = __builtin_bit_cast(f16x8, row[2 * c + half]);
         bl[j] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
       }
+      if constexpr (DBG == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -187,14 +200,18 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
     // even tile kt is in buffer 0; stage odd tile kt+1 into buffer 1 (last read in iteration
     // kt-1: every wave has passed that barrier).  Staging past the last tile is harmless.
     compute(0);
-    lstore(ra0, rw0, 1);
-    if constexpr (PF == 2) gload(ra0, rw0, kt + 3);
-    else gload(ra1, rw1, kt + 2);
+    if constexpr (DBG != 2) {
+      lstore(ra0, rw0, 1);
+      if constexpr (PF == 2) gload(ra0, rw0, kt + 3);
+      else gload(ra1, rw1, kt + 2);
+    }
     __syncthreads();
     if (kt + 1 < nk) compute(1);
-    lstore(ra1, rw1, 0);
-    if constexpr (PF == 2) gload(ra1, rw1, kt + 4);
-    else gload(ra0, rw0, kt + 3);
+    if constexpr (DBG != 2) {
+      lstore(ra1, rw1, 0);
+      if constexpr (PF == 2) gload(ra1, rw1, kt + 4);
+      else gload(ra0, rw0, kt + 3);
+    }
     __syncthreads();
   }
 
@@ -250,12 +267,28 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+template <int DBG>
+static void launch_dbg(const GemmSplitArgs& p, hipStream_t s) {
+  constexpr int smem = 2 * (256 + 128) * 9 * 16;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<EPI_BIAS, 2, 4, 1, DBG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+  hipLaunchKernelGGL((gemm_f16x3_kernel<EPI_BIAS, 2, 4, 1, DBG>), dim3(tiles), dim3(512), smem, s, p);
+}
+
 void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
                        const float* resid, float* C, int M, int N, int K, hipStream_t s) {
   static const int al = env_int("FDMI_GEMM_AL", 1) == 0 ? 0 : 1;
+  static const int dbg = env_int("FDMI_GEMM_DBG", 0);  // ablation only (see DBG above)
   static const int bm = env_int("FDMI_GEMM_BM", 256) == 128 ? 128 : 256;
   const float a_scale = 16.0f;  // |a| < 4094 stays finite in fp16; lo of |a| > 0.008 is a normal fp16
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
+  if (dbg >= 1 && dbg <= 3) {
+    if (dbg == 1) launch_dbg<1>(p, s);
+    else if (dbg == 2) launch_dbg<2>(p, s);
+    else launch_dbg<3>(p, s);
+    return;
+  }
   if (bm == 256) {
     if (al == 0) launch_pf<4, 0>(epilogue, p, s);
     else launch_pf<4, 1>(epilogue, p, s);

@@ -164,6 +164,10 @@ int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, 
 int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, const float* W, const float* bias,
                  const float* resid, float* C, int M, int N, int K);
 
+/* Average launch time (ms) of the bias-epilogue token GEMM of the given precision on pseudo-random
+ * operands, `reps` back-to-back launches bracketed by hipEvents (kernel micro-benchmark / ablations). */
+int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int reps, double* ms_per_launch);
+
 /* ---- measurement ---- */
 
 /* When n > 0, every n-th reverse step of fd_sample* is launched eagerly with a
