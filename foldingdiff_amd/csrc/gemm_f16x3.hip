@@ -70,6 +70,55 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
   lo = __builtin_bit_cast(u32x4, b);
 }
 
+// Epilogue of one wave's 64 x 64 accumulator block (2 x 2 MFMA tiles) at (row0, col0).  All loads
+// (bias, residual) are unconditional with clamped indices and every value is finished BEFORE the
+// predicated stores: a load result consumed inside a per-row branch makes hipcc put
+// `s_waitcnt vmcnt(0)` in front of every store, which serialises the stores and drains the
+// prefetched loads of the next tile.
+template <int EPI>
+__device__ __forceinline__ void store_tile(const GemmSplitArgs& p, const f32x16 (&acc)[2][2], int row0, int col0,
+                                           int half, int l31) {
+  const bool full = row0 + 64 <= p.M && col0 + 64 <= p.N;
+  float bz[2];
+  int colc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + j * 32 + l31;
+    colc[j] = col < p.N ? col : p.N - 1;
+    bz[j] = p.bias[colc[j]];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + j * 32 + l31;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int rowc = row < p.M ? row : p.M - 1;
+        v[r] = acc[i][j][r] * p.out_scale + bz[j];
+        if constexpr (EPI == EPI_BIAS_GELU) v[r] = gelu_erf16(v[r]);
+        if constexpr (EPI == EPI_BIAS_RESID) v[r] += p.resid[(size_t)rowc * p.N + colc[j]];
+      }
+      if (full) {  // wave-uniform: interior block, straight-line stores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          p.C[(size_t)row * p.N + col] = v[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));  // values are final before any branch
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < p.M && col < p.N) p.C[(size_t)row * p.N + col] = v[r];
+        }
+      }
+    }
+}
+
 // WM = waves along M: 4 -> 256 x 128 block, 8 waves, one block per CU;
 //                     2 -> 128 x 128 block, 4 waves, two independent blocks per CU (their barrier /
 //                          staging phases overlap each other's MFMA phases).
@@ -216,25 +265,172 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
   }
 
   // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  store_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, half, l31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant: one workgroup per CU walks a list of output tiles and treats the
+// (tile, k-tile) pairs as ONE continuous stream through the same two-deep register prefetch and
+// LDS double buffer.  The first k-tiles of the next output tile are therefore already in flight /
+// in LDS while the epilogue of the current tile issues its (asynchronous) stores: neither the
+// per-tile load latency nor the store drain is exposed any more (with one 8-wave workgroup per
+// CU nothing else could hide them -- measured: staging alone 184 us, MFMA loop + epilogue alone
+// 236 us, both together 304 us on the QKV shape in the non-persistent kernel).
+// Requires an even number of k-tiles (buffer parity is then the same for every tile).
+// Tiles are dealt XCD-aware: XCD x (= workgroups with id % 8 == x) owns a contiguous range of the
+// n-fastest tile order, and its workgroups take neighbouring tiles at the same time (shared A panel
+// in that XCD's L2).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p) {
+  constexpr int BM = 256, BN = 128, BK = 32, RQ = 9, NTHR = 512;
+  constexpr int STAGE = (BM + BN) * RQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int K = p.K, nk = K / BK;
+  // this workgroup's tiles: first, first + stride, ... (cnt of them)
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int lo = (int)((long long)ntiles * xcd / 8), hi = (int)((long long)ntiles * (xcd + 1) / 8);
+  const int first = lo + j, stride = per;
+  const int cnt = first < hi ? (hi - first + stride - 1) / stride : 0;
+  if (cnt == 0) return;
+  const int G = cnt * nk;  // length of the (tile, k-tile) stream
+
+  const int arow = tid >> 2, au = tid & 3;        // A: two (row, 8-float octet) pairs per thread
+  const int arow2 = arow + NTHR / 4;
+  const int wrow = tid >> 2, wpart = 2 * (tid & 3);  // W image: 2 x 16 B per thread
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + l31;
-      if (col < p.N) {
-        const float bz = p.bias[col];
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < p.M) {
-            float v = acc[i][j][r] * p.out_scale + bz;
-            if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf16(v);
-            if constexpr (EPI == EPI_BIAS_RESID) v += p.resid[(size_t)row * p.N + col];
-            p.C[(size_t)row * p.N + col] = v;
-          }
-        }
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+  };
+  zero_acc();
+
+  float4 ra0[4], ra1[4];
+  u32x4 rw0[2], rw1[2];
+  // unconditional loads, indices clamped (see the non-persistent kernel)
+  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[2], int g) {
+    g = g < G ? g : G - 1;
+    const int ti = g / nk, kt = g - ti * nk;
+    const int tile = first + ti * stride;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int r1 = m0 + arow < p.M ? m0 + arow : p.M - 1, r2 = m0 + arow2 < p.M ? m0 + arow2 : p.M - 1;
+    const float* a1 = p.A + (size_t)r1 * K + kt * BK + 8 * au;
+    const float* a2 = p.A + (size_t)r2 * K + kt * BK + 8 * au;
+    ra[0] = *reinterpret_cast<const float4*>(a1);
+    ra[1] = *reinterpret_cast<const float4*>(a1 + 4);
+    ra[2] = *reinterpret_cast<const float4*>(a2);
+    ra[3] = *reinterpret_cast<const float4*>(a2 + 4);
+    const u32x4* w = p.Wp + ((size_t)(n0 + wrow) * nk + kt) * 8 + wpart;
+    rw[0] = w[0];
+    rw[1] = w[1];
+  };
+  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[2], int buf) {
+    u32x4* S = smem + buf * STAGE;
+    u32x4 h0, l0, h1, l1;
+    split8(ra[0], ra[1], p.a_scale, h0, l0);
+    split8(ra[2], ra[3], p.a_scale, h1, l1);
+    u32x4* row = S + arow * RQ;
+    u32x4* rowb = S + arow2 * RQ;
+    row[au] = h0; row[4 + au] = l0; rowb[au] = h1; rowb[4 + au] = l1;
+    u32x4* wr = S + (BM + wrow) * RQ + wpart;
+    wr[0] = rw[0];
+    wr[1] = rw[1];
+  };
+  auto compute = [&](int buf) {
+    const u32x4* S = smem + buf * STAGE;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4* row = S + (wm * 64 + i * 32 + l31) * RQ;
+        ah[i] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+        al[i] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
       }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const u32x4* row = S + (BM + wn * 64 + jj * 32 + l31) * RQ;
+        bh[jj] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+        bl[jj] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
     }
+  };
+  auto epilogue = [&](int ti) {
+    const int tile = first + ti * stride;
+    store_tile<EPI>(p, acc, (tile / tiles_n) * BM + wm * 64, (tile % tiles_n) * BN + wn * 64, half, l31);
+  };
+
+  // stream positions: even g -> LDS buffer 0 / register set 1, odd g -> buffer 1 / set 0
+  auto pair = [&](int g) {
+    compute(0);
+    lstore(ra0, rw0, 1);
+    gload(ra0, rw0, g + 3);
+    __syncthreads();
+    compute(1);
+    lstore(ra1, rw1, 0);  // position g+2: for the last k-pair of a tile this is already the NEXT tile
+    gload(ra1, rw1, g + 4);
+    __syncthreads();
+  };
+  gload(ra1, rw1, 0);
+  lstore(ra1, rw1, 0);
+  gload(ra0, rw0, 1);
+  gload(ra1, rw1, 2);
+  __syncthreads();
+  // The first and the last k-pair of every tile are peeled so that the steady-state loop has the
+  // same number of younger memory operations on every path into it: hipcc then keeps exact counted
+  // s_waitcnt vmcnt(N) there, and the epilogue's stores are never drained by a conservative wait.
+  const int npairs = nk / 2;  // >= 2 (host guarantees)
+  for (int ti = 0; ti < cnt; ++ti) {
+    const int g0 = ti * nk;
+    pair(g0);
+    for (int pi = 1; pi < npairs - 1; ++pi) pair(g0 + 2 * pi);
+    pair(g0 + nk - 2);
+    epilogue(ti);  // stores drain under the next tile's MFMAs; its first k-tiles are already staged
+    zero_acc();
+  }
+}
+
+template <int EPI>
+static void launch_persist(const GemmSplitArgs& p, hipStream_t s) {
+  constexpr int smem = 2 * (256 + 128) * 9 * 16;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_persist_kernel<EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int ntiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+  int grid = n_cu / 8 * 8;               // one workgroup per CU, a multiple of the 8 XCDs
+  if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+  hipLaunchKernelGGL((gemm_f16x3_persist_kernel<EPI>), dim3(grid), dim3(512), smem, s, p);
 }
 
 template <int EPI, int PF, int WM, int AL>
@@ -283,6 +479,15 @@ void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_sca
   static const int bm = env_int("FDMI_GEMM_BM", 256) == 128 ? 128 : 256;
   const float a_scale = 16.0f;  // |a| < 4094 stays finite in fp16; lo of |a| > 0.008 is a normal fp16
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
+  static const int persist = env_int("FDMI_GEMM_PERSIST", 1);
+  if (persist && dbg == 0 && (K / 32) % 2 == 0 && K >= 128) {
+    switch (epilogue) {
+      case EPI_BIAS: launch_persist<EPI_BIAS>(p, s); break;
+      case EPI_BIAS_GELU: launch_persist<EPI_BIAS_GELU>(p, s); break;
+      default: launch_persist<EPI_BIAS_RESID>(p, s); break;
+    }
+    return;
+  }
   if (dbg >= 1 && dbg <= 3) {
     if (dbg == 1) launch_dbg<1>(p, s);
     else if (dbg == 2) launch_dbg<2>(p, s);

@@ -199,22 +199,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
       }
     }
   } else {
+    const bool full = m0 + (wm + 1) * MT * 32 <= p.M && n0 + (wn + 1) * NT * 32 <= p.N;
+    // all loads unconditional (clamped) and every value finished before the predicated stores: a
+    // load result consumed inside a per-row branch makes hipcc emit `s_waitcnt vmcnt(0)` in front of
+    // every store, serialising them
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int col = n0 + (wn * NT + j) * 32 + l31;
-        if (col < p.N) {
-          const float bz = p.bias[col];
+        const int colc = col < p.N ? col : p.N - 1;
+        const float bz = p.bias[colc];
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int rowc = row < p.M ? row : p.M - 1;
+          v[r] = acc[i][j][r] + bz;
+          if constexpr (EPI == EPI_BIAS_GELU) v[r] = gelu_erf(v[r]);
+          if constexpr (EPI == EPI_BIAS_RESID) v[r] += p.resid[(size_t)rowc * p.N + colc];
+        }
+        if (full) {  // wave-uniform: interior block, straight-line stores
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < p.M) {
-              float v = acc[i][j][r] + bz;
-              if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-              if constexpr (EPI == EPI_BIAS_RESID) v += p.resid[(size_t)row * p.N + col];
-              p.C[(size_t)row * p.N + col] = v;
-            }
+            p.C[(size_t)row * p.N + col] = v[r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(v[r]));  // values are final before any branch
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < p.M && col < p.N) p.C[(size_t)row * p.N + col] = v[r];
           }
         }
       }
