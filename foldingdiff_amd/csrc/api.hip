@@ -49,7 +49,7 @@ struct SplitW {
 };
 
 struct LayerDev {
-  SplitW wqkv_s, wo_s, wi_s, wd_s;
+  SplitW wqkv_s, wo_s, wi_s, wd_s, demb_s;
   float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
   float *wo = nullptr, *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr;
   float *wi = nullptr, *bi = nullptr, *wd = nullptr, *bd = nullptr, *ln2g = nullptr, *ln2b = nullptr;
@@ -346,7 +346,7 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
     PROF(KC_GEMM_QKV, gemm(m, EPI_BIAS, w.h, lw.wqkv, lw.wqkv_s, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
     bool ok = true;
     PROF(KC_ATTN, ok = (m->precision == FD_PREC_F16X3 && m->attn_f16)
-                        ? launch_attention_f16x3(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s)
+                        ? launch_attention_f16x3(w.qkv, lw.demb_s.p, lw.demb_s.scale, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s)
                         : launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
     if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by the fp32 kernel (max 128)", L);
     bool fused = false;
@@ -602,6 +602,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     if (c.pos_type == FD_POS_RELATIVE_KEY) {
       NEED(de, p + "attention.self.distance_embedding.weight");
       UP(lw.demb, de);
+      if (precision == FD_PREC_F16X3)
+        if (int rc = upload_split(m, &lw.demb_s, de->data.data(), 2 * c.max_pos - 1, kHeadDim)) return rc;
     }
     NEED(wo, p + "attention.output.dense.weight");
     NEED(bo, p + "attention.output.dense.bias");

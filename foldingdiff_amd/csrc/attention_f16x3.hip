@@ -4,14 +4,17 @@
 // x*s = hi + lo (fp16 each, s a power of two) and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is
 // issued as three v_mfma_f32_32x32x16_f16 into one fp32 accumulator (see gemm_f16x3.hip).
 //
-// One 8-wave workgroup per (sequence, pair of heads, group of 128 queries); a wave owns one 32-query
-// row block and walks the key tiles (128 keys each) with a flash-style online softmax, so any
-// L <= max_position_embeddings fits (L <= 128: a single tile).
+// One 4-wave workgroup per (sequence, head, group of 128 queries); a wave owns one 32-query row block
+// and walks the key tiles (128 keys each) with a flash-style online softmax, so any
+// L <= max_position_embeddings fits (L <= 128: a single tile).  53 KB of LDS per workgroup: two to
+// three workgroups share a CU, so one's LDS fill overlaps the others' MFMA / softmax phases.
 //   LDS (fp16 hi|lo row images, rows padded so the 16/8-byte operand fetches are conflict free):
-//     K   [2 heads][LP keys][hi d0-31 | lo d0-31]      144 B rows
-//     E   [2*LP band rows][hi | lo]                     144 B rows   (relative_key only; shared by both heads)
-//     Vt  [2 heads][32 d][hi key0..LP-1 | lo ...]       transposed while filling: keys contiguous
-//     Rw  [8 waves][32 queries][32 fp32 (+4 pad)]       scratch for the relative-key skew
+//     K   [LP keys][hi d0-31 | lo d0-31]      144 B rows
+//     Vt  [32 d][hi key0..LP-1 | lo ...]       transposed while filling: keys contiguous
+//     Rw  [4 waves][32 queries][32 fp32 (+4 pad)]       scratch for the relative-key skew
+//   The distance table E is split once on the host (fd_finalize) into 128-byte row images
+//   [m][hi d0-31 | lo d0-31] and its band rows are fetched as MFMA operands straight from L2
+//   (32 KB per layer, shared by every workgroup).
 //   * S^T tile (keys x queries) = K . Q^T : A = K rows (LDS), B = Q (registers).  The transposed
 //     form puts a query's scores in ONE lane pair: softmax max/sum are in-register reductions
 //     plus a single cross-half shuffle, and P is already laid out as the A operand of P.V
@@ -37,12 +40,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace a16 {
 
-constexpr int HPB = 2;          // heads per workgroup
+constexpr int HPB = 1;          // heads per workgroup
 constexpr int KROW = 144;       // bytes per K / E row image: 64 B hi + 64 B lo + 16 B pad
 constexpr int RLD = 36;         // floats per row of the R scratch
 constexpr float QS = 16.0f;     // power-of-two operand scales (exact); undone in fp32 after the MFMAs
 constexpr float KS = 16.0f;
-constexpr float ES = 1024.0f;   // distance-embedding rows are ~0.02 in magnitude
 constexpr float PS = 1024.0f;   // probabilities are <= 1
 constexpr float VS = 16.0f;
 
@@ -73,8 +75,8 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
 }
 
 template <int T, bool REL>
-__global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __restrict__ qkv,
-                                                               const float* __restrict__ demb,
+__global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* __restrict__ qkv,
+                                                               const u32x4* __restrict__ demb, float r_scale,
                                                                const int* __restrict__ lens, float* __restrict__ ctx,
                                                                int L, int H, int maxpos) {
   constexpr int LP = 32 * T;        // keys per key tile = queries per query group
@@ -82,8 +84,7 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
   constexpr int VROW = 4 * LP + 8;  // bytes per Vt row: LP hi + LP lo halves + 8 B pad (b64 reads conflict free)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
   unsigned char* Ks = smem16;                               // [HPB][LP] rows of KROW bytes
-  unsigned char* Es = Ks + HPB * LP * KROW;                 // [2*LP] rows of KROW bytes (REL only)
-  unsigned char* Vt = Es + (REL ? 2 * LP * KROW : 0);       // [HPB][32] rows of VROW bytes
+  unsigned char* Vt = Ks + HPB * LP * KROW;                 // [HPB][32] rows of VROW bytes
   float* Rs = reinterpret_cast<float*>(Vt + HPB * 32 * VROW);  // [4*HPB waves][32][RLD]   (REL only)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -136,12 +137,12 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
     for (int idx = tid; idx < HPB * LP * 4; idx += NT) {
       const int fh = idx / (LP * 4), rem = idx % (LP * 4);
       const int r = rem >> 2, oct = rem & 3;
-      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
-      if (r0 + r < L && h0 + fh < H) {
-        const float* src = seq + (size_t)(r0 + r) * ld + d + (h0 + fh) * 32 + oct * 8;
-        p = *reinterpret_cast<const float4*>(src);
-        q = *reinterpret_cast<const float4*>(src + 4);
-      }
+      // unconditional loads (row clamped), zeroed by select: no branch around a load
+      const bool ok = r0 + r < L && h0 + fh < H;
+      const float* src = seq + (size_t)(r0 + r < L ? r0 + r : L - 1) * ld + d + (h0 + fh < H ? h0 + fh : H - 1) * 32 + oct * 8;
+      float4 p = *reinterpret_cast<const float4*>(src);
+      float4 q = *reinterpret_cast<const float4*>(src + 4);
+      if (!ok) p = q = make_float4(0.f, 0.f, 0.f, 0.f);
       f16x8 hi, lo;
       split8(p, q, KS, hi, lo);
       unsigned char* row = Ks + (size_t)(fh * LP + r) * KROW;
@@ -152,12 +153,12 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
     for (int idx = tid; idx < HPB * (LP / 2) * 8; idx += NT) {
       const int fh = idx / ((LP / 2) * 8), rem = idx % ((LP / 2) * 8);
       const int kp = rem >> 3, c4 = rem & 7;
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (h0 + fh < H) {
-        const float* src = seq + 2 * d + (h0 + fh) * 32 + c4 * 4;
-        if (r0 + 2 * kp < L) v0 = *reinterpret_cast<const float4*>(src + (size_t)(r0 + 2 * kp) * ld);
-        if (r0 + 2 * kp + 1 < L) v1 = *reinterpret_cast<const float4*>(src + (size_t)(r0 + 2 * kp + 1) * ld);
-      }
+      const float* src = seq + 2 * d + (h0 + fh < H ? h0 + fh : H - 1) * 32 + c4 * 4;
+      const int k0 = r0 + 2 * kp, k1 = k0 + 1;
+      float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)(k0 < L ? k0 : L - 1) * ld);
+      float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(k1 < L ? k1 : L - 1) * ld);
+      if (k0 >= L || h0 + fh >= H) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k1 >= L || h0 + fh >= H) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
       const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -168,26 +169,6 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
         unsigned char* row = Vt + (size_t)(fh * 32 + c4 * 4 + i) * VROW;
         *reinterpret_cast<unsigned*>(row + 4 * kp) = __builtin_bit_cast(unsigned, hi);
         *reinterpret_cast<unsigned*>(row + 2 * LP + 4 * kp) = __builtin_bit_cast(unsigned, lo);
-      }
-    }
-    if constexpr (REL) {
-      // Es[e] = E[m_min + e]; for group-relative l', r' in [0, LP): m = l' - r' + (maxpos-1) + LP*(qg-kt),
-      // so m_min = (maxpos-1) - (LP-1) + LP*(qg-kt); rows outside the table are zero (never selected
-      // for a valid (l, r) pair because L <= max_position_embeddings)
-      const int m_min = (maxpos - 1) - (LP - 1) + LP * (qg - kt);
-      for (int idx = tid; idx < 2 * LP * 4; idx += NT) {
-        const int e = idx >> 2, oct = idx & 3, m = e + m_min;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
-        if (m >= 0 && m <= 2 * (maxpos - 1)) {
-          const float* src = demb + (size_t)m * 32 + oct * 8;
-          p = *reinterpret_cast<const float4*>(src);
-          q = *reinterpret_cast<const float4*>(src + 4);
-        }
-        f16x8 hi, lo;
-        split8(p, q, ES, hi, lo);
-        unsigned char* row = Es + (size_t)e * KROW;
-        *reinterpret_cast<u32x4*>(row + oct * 16) = __builtin_bit_cast(u32x4, hi);
-        *reinterpret_cast<u32x4*>(row + 64 + oct * 16) = __builtin_bit_cast(u32x4, lo);
       }
     }
     __syncthreads();
@@ -216,20 +197,26 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
       for (int r = 0; r < 16; ++r) sacc[t][r] *= S_SCALE;
     if constexpr (REL) {
       // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31 (band origin: this
-      // wave's row block, i.e. Es row 32*wq + 32q + l31).  S^T tile t element (key kl, query ql)
+      // wave's row block).  S^T tile t element (key kl, query ql)
       // needs band column j = ql - kl + 31 of the tile pair (q = T-1-t, q+1):  j < 32 -> tile q,
       // else tile q+1 column j-32.
-      constexpr float R_SCALE = 1.0f / (QS * ES);
+      // band row of R tile q, column l31:  m = (maxpos-1) - (LP-1) + LP*(qg-kt) + 32*wq + 32q + l31.
+      // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos), so
+      // the index is clamped instead of predicated (keeps the loads unconditional).
+      const float R_SCALE = r_scale;  // 1 / (QS * table scale)
+      const int m_base = (maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31;
 #pragma unroll
       for (int q = 0; q <= T; ++q) {
         f32x16 racc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-        const unsigned char* row = Es + (size_t)(32 * wq + 32 * q + l31) * KROW;
+        int m = m_base + 32 * q;
+        m = m < 0 ? 0 : (m > 2 * (maxpos - 1) ? 2 * (maxpos - 1) : m);
+        const u32x4* row = demb + (size_t)m * 8;  // 128-byte image: units 0-3 hi d0-31, 4-7 lo
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const f16x8 eh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 32 * c + 16 * half));
-          const f16x8 el = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 64 + 32 * c + 16 * half));
+          const f16x8 eh = __builtin_bit_cast(f16x8, row[2 * c + half]);
+          const f16x8 el = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
           racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], eh, racc, 0, 0, 0);
           racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], el, racc, 0, 0, 0);
           racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[c], eh, racc, 0, 0, 0);
@@ -339,10 +326,10 @@ __global__ __launch_bounds__(256 * HPB) void attn_f16x3_kernel(const float* __re
 }
 
 template <int T, bool REL>
-static void launch_t(const float* qkv, const float* demb, const int* lens, float* ctx, int B, int L, int H, int maxpos,
-                     hipStream_t s) {
+static void launch_t(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
+                     int maxpos, hipStream_t s) {
   constexpr int LP = 32 * T;
-  const size_t smem = (size_t)HPB * LP * KROW + (REL ? 2 * LP * KROW : 0) + (size_t)HPB * 32 * (4 * LP + 8) +
+  const size_t smem = (size_t)HPB * LP * KROW + (size_t)HPB * 32 * (4 * LP + 8) +
                       (REL ? sizeof(float) * 4 * HPB * 32 * RLD : 0);
   static bool attr_set = false;
   if (!attr_set) {
@@ -352,21 +339,22 @@ static void launch_t(const float* qkv, const float* demb, const int* lens, float
   }
   const int hgroups = (H + HPB - 1) / HPB;
   const int nqg = (L + LP - 1) / LP;
-  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv, demb, lens,
-                     ctx, L, H, maxpos);
+  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
+                     static_cast<const u32x4*>(demb), r_scale, lens, ctx, L, H, maxpos);
 }
 
 }  // namespace a16
 
-bool launch_attention_f16x3(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
-                            int maxpos, hipStream_t s) {
+bool launch_attention_f16x3(const float* qkv, const void* dist_emb_split, float table_scale, const int* lens, float* ctx,
+                            int B, int L, int H, int maxpos, hipStream_t s) {
   if (L < 1) return false;
   const int T = L > 128 ? 4 : (L + 31) / 32;  // long sequences: 128-key tiles x 128-query groups, online softmax
-  const bool rel = dist_emb != nullptr;
-#define FD_ATTN16_CASE(TT)                                                             \
-  case TT:                                                                             \
-    if (rel) a16::launch_t<TT, true>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);    \
-    else a16::launch_t<TT, false>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);       \
+  const bool rel = dist_emb_split != nullptr;
+  const float r_scale = 1.0f / (a16::QS * table_scale);
+#define FD_ATTN16_CASE(TT)                                                                              \
+  case TT:                                                                                              \
+    if (rel) a16::launch_t<TT, true>(qkv, dist_emb_split, r_scale, lens, ctx, B, L, H, maxpos, s);      \
+    else a16::launch_t<TT, false>(qkv, nullptr, 1.f, lens, ctx, B, L, H, maxpos, s);                    \
     break;
   switch (T) {
     FD_ATTN16_CASE(1)

@@ -48,8 +48,10 @@ bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* le
                           int maxpos, hipStream_t s);
 
 // Same contract, contractions as fp16 hi/lo split triples on v_mfma_f32_32x32x16_f16 (fp32-class accuracy).
-bool launch_attention_f16x3(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
-                            int maxpos, hipStream_t s);
+// dist_emb_split: the layer's [2*maxpos-1, 32] table pre-split into 128-byte fp16 row images (hi x32 | lo x32),
+// scaled by the power of two table_scale (null for absolute positions).
+bool launch_attention_f16x3(const float* qkv, const void* dist_emb_split, float table_scale, const int* lens,
+                            float* ctx, int B, int L, int H, int maxpos, hipStream_t s);
 
 // K8 tail + K9: per token  y = do_ln ? LN(g)*gamma+beta : g ;  eps = y W2^T + b2 ;
 //   x' = wrap_if_angle( c1[t] * (x - beta[t]*eps / c3[t]) + (t>0 ? sigma[t]*z : 0) )
