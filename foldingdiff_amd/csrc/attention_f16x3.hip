@@ -226,25 +226,28 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // scratch row = query l31 (this lane); gather into the two S^T tiles that use band tile q
-        if (q < T) {  // as the low tile of S^T tile t = T-1-q : j = l31 - kl + 31 <= 31  <=>  l31 <= kl
-          const int t = T - 1 - q;
+        // scratch row = query l31 (this lane).  Band column j = l31 - kl + 31 of the tile PAIR
+        // (q, q+1) lives in tile q for j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise:
+        // both cases read scratch column j & 31, so one branch-free set of 16 reads serves the two
+        // S^T tiles that use band tile q (selects, no exec-mask branches around LDS reads).
+        float gth[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+          gth[r] = Rw[l31 * RLD + ((l31 - kl + 31) & 31)];
+        }
+        if (q < T) {  // low tile of S^T tile t = T-1-q
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int j = l31 - kl + 31;
-            const float v = Rw[l31 * RLD + (j & 31)];
-            if (j < 32) sacc[t][r] += v;
+            sacc[T - 1 - q][r] += (l31 <= kl) ? gth[r] : 0.f;
           }
         }
-        if (q > 0) {  // as the high tile of S^T tile t = T-q : column j - 32 = l31 - kl - 1 >= 0
-          const int t = T - q;
+        if (q > 0) {  // high tile of S^T tile t = T-q
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int j = l31 - kl + 31;
-            const float v = Rw[l31 * RLD + (j & 31)];
-            if (j >= 32) sacc[t][r] += v;
+            sacc[T - q][r] += (l31 > kl) ? gth[r] : 0.f;
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
