@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-ln", type=int, default=0)
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM arithmetic (default: library default)")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the extra single pass in exact-fp32 MFMA mode that is reported next to the headline (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,6 +257,20 @@ def main():
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
                         "launches": v["launches"]} for k, v in kernels.items()},
     }
+    if world == 1 and model.precision != "f32" and not args.no_exact_f32:
+        # the same workload with every contraction on v_mfma_f32_32x32x2_f32 (bitwise-fp32 products), one pass
+        model.set_precision("f32")
+        model.prepare(betas)
+        _binding.check(lib.fd_profile_every(model._handle, 0))
+        one_pass(4242)
+        sync_all()
+        t1 = time.perf_counter()
+        one_pass(4243)
+        sync_all()
+        dt = time.perf_counter() - t1
+        result["exact_f32_mode"] = {"value": B / dt, "unit": "backbones/s", "ms_per_step": dt * 1e3,
+                                    "frac_of_f32_mfma_peak": (B / dt) * flop_per_backbone / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                    "note": "FD_PREC_F32: all GEMM/attention products on v_mfma_f32_32x32x2_f32, 1 timed pass"}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(L, T)
     print(json.dumps(result), flush=True)

@@ -33,7 +33,7 @@ import torch
 from . import _binding, beta_schedules
 from .datasets import FEATURE_SET_NAMES_TO_ANGULARITY
 
-DEFAULT_PRECISION = "f32"
+DEFAULT_PRECISION = "f16x3"  # fp32-class accuracy (measured <= the exact-fp32 kernels' error), ~2x faster
 TIME_ENCODING = Literal["gaussian_fourier", "sinusoidal"]
 DECODER_HEAD = Literal["mlp", "linear"]
 
