@@ -47,15 +47,12 @@ constexpr float QS = 16.0f;     // power-of-two operand scales (exact); undone i
 constexpr float KS = 16.0f;
 constexpr float PS = 1024.0f;   // probabilities are <= 1
 constexpr float VS = 16.0f;
+constexpr float kLog2eOverSqrtD = 1.44269504088896341f * 0.17677669529663687f;  // log2(e) / sqrt(32)
+constexpr float kMaskLog2 = -10000.0f * 1.44269504088896341f;                     // (1 - mask) * -10000, log2 domain
 
-__device__ __forceinline__ float exp_neg(float x) {
-  const float LOG2E_HI = 1.44269502162933349609375f, LOG2E_LO = 1.925963033500011e-08f;
-  x = fmaxf(x, -200.0f);
-  const float t = x * LOG2E_HI;
-  const float err = fmaf(x, LOG2E_HI, -t) + x * LOG2E_LO;
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, err * 0.693147180559945f, e);
-}
+// 2^x for x <= 0 on v_exp_f32 (1 ulp).  x = -inf (padding keys, first-tile rescale) gives exactly 0;
+// masked keys (about -14427 in the log2 domain) underflow to exactly 0 as exp(-10000) does in the reference.
+__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ void split1(float x, float s, _Float16& hi, _Float16& lo) {
   const float xs = x * s;
@@ -203,7 +200,9 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
         sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
       }
     }
-    constexpr float S_SCALE = 1.0f / (QS * KS);
+    // Scores are carried in the log2 domain, pre-divided by sqrt(head size): one multiply here (and
+    // one on the band values below) replaces the separate /sqrt(32) and the x*log2(e) inside exp().
+    constexpr float S_SCALE = kLog2eOverSqrtD / (QS * KS);
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -268,28 +267,36 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
         __builtin_amdgcn_wave_barrier();
       }
     }
-    // scale, mask, online softmax over keys: this lane + its partner (lane ^ 32) hold one query's scores
+    // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one
+    // query's scores.  Key tiles without masked / padding keys (wave-uniform test) skip the mask ops.
     float mt = -INFINITY;
+    if (r0 + LP <= len) {
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float sc = sacc[t][r] * 0.17677669529663687f;  // / sqrt(attention_head_size = 32)
-        if (key >= len) sc += -10000.0f;               // (1 - mask) * -10000   (modelling.py:452)
-        if (key >= L) sc = -INFINITY;                  // tile padding: not a key at all
-        sacc[t][r] = sc;
-        mt = fmaxf(mt, sc);
-      }
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float sc = sacc[t][r];
+          if (key >= len) sc += kMaskLog2;   // (1 - mask) * -10000   (modelling.py:452)
+          if (key >= L) sc = -INFINITY;      // tile padding: not a key at all
+          sacc[t][r] = sc;
+          mt = fmaxf(mt, sc);
+        }
+    }
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp_neg(m_run - m_new);  // first tile: exp(-inf) -> 0 (accumulators are 0 anyway)
+    const float alpha = exp2_neg(m_run - m_new);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pexp = exp_neg(sacc[t][r] - m_new);
+        const float pexp = exp2_neg(sacc[t][r] - m_new);
         sacc[t][r] = pexp;
         psum += pexp;
       }
@@ -367,7 +374,7 @@ bool launch_attention_f16x3(const float* qkv, const void* dist_emb_split, float 
   if (L < 1) return false;
   const int T = L > 128 ? 4 : (L + 31) / 32;  // long sequences: 128-key tiles x 128-query groups, online softmax
   const bool rel = dist_emb_split != nullptr;
-  const float r_scale = 1.0f / (a16::QS * table_scale);
+  const float r_scale = a16::kLog2eOverSqrtD / (a16::QS * table_scale);  // band values land in the same log2 / sqrt(d) domain as the scores
 #define FD_ATTN16_CASE(TT)                                                                              \
   case TT:                                                                                              \
     if (rel) a16::launch_t<TT, true>(qkv, dist_emb_split, r_scale, lens, ctx, B, L, H, maxpos, s);      \

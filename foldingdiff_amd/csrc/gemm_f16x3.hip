@@ -280,9 +280,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_kernel(GemmSplitArgs p) {
 // Tiles are dealt XCD-aware: XCD x (= workgroups with id % 8 == x) owns a contiguous range of the
 // n-fastest tile order, and its workgroups take neighbouring tiles at the same time (shared A panel
 // in that XCD's L2).
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p) {
-  constexpr int BM = 256, BN = 128, BK = 32, RQ = 9, NTHR = 512;
+// VAR (compute-phase schedule): 0 = fetch the fragments of one k16 step, 12 MFMAs, next step;
+//                               1 = fetch the fragments of both k16 steps up front, then 24 MFMAs;
+//                               2 = as 1 with s_setprio 1 around the MFMA cluster.
+template <int EPI, int VAR = 0, int WM = 4>
+__global__ __launch_bounds__(128 * WM) void gemm_f16x3_persist_kernel(GemmSplitArgs p) {
+  constexpr int BM = 64 * WM, BN = 128, BK = 32, RQ = 9, NTHR = 128 * WM;
+  constexpr int WU = BN * 8 / NTHR;  // W image units (16 B) per thread per k-tile
   constexpr int STAGE = (BM + BN) * RQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p
 
   const int arow = tid >> 2, au = tid & 3;        // A: two (row, 8-float octet) pairs per thread
   const int arow2 = arow + NTHR / 4;
-  const int wrow = tid >> 2, wpart = 2 * (tid & 3);  // W image: 2 x 16 B per thread
+  const int wrow = tid / (8 / WU), wpart = WU * (tid % (8 / WU));  // W image: WU x 16 B per thread
 
   f32x16 acc[2][2];
   auto zero_acc = [&]() {
@@ -317,9 +321,9 @@ __global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p
   zero_acc();
 
   float4 ra0[4], ra1[4];
-  u32x4 rw0[2], rw1[2];
+  u32x4 rw0[WU], rw1[WU];
   // unconditional loads, indices clamped (see the non-persistent kernel)
-  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[2], int g) {
+  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[WU], int g) {
     g = g < G ? g : G - 1;
     const int ti = g / nk, kt = g - ti * nk;
     const int tile = first + ti * stride;
@@ -332,10 +336,10 @@ __global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p
     ra[2] = *reinterpret_cast<const float4*>(a2);
     ra[3] = *reinterpret_cast<const float4*>(a2 + 4);
     const u32x4* w = p.Wp + ((size_t)(n0 + wrow) * nk + kt) * 8 + wpart;
-    rw[0] = w[0];
-    rw[1] = w[1];
+#pragma unroll
+    for (int i = 0; i < WU; ++i) rw[i] = w[i];
   };
-  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[2], int buf) {
+  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[WU], int buf) {
     u32x4* S = smem + buf * STAGE;
     u32x4 h0, l0, h1, l1;
     split8(ra[0], ra[1], p.a_scale, h0, l0);
@@ -344,38 +348,74 @@ __global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p
     u32x4* rowb = S + arow2 * RQ;
     row[au] = h0; row[4 + au] = l0; rowb[au] = h1; rowb[4 + au] = l1;
     u32x4* wr = S + (BM + wrow) * RQ + wpart;
-    wr[0] = rw[0];
-    wr[1] = rw[1];
+#pragma unroll
+    for (int i = 0; i < WU; ++i) wr[i] = rw[i];
   };
   auto compute = [&](int buf) {
     const u32x4* S = smem + buf * STAGE;
+    if constexpr (VAR == 0) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      f16x8 ah[2], al[2], bh[2], bl[2];
+      for (int c = 0; c < 2; ++c) {
+        f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const u32x4* row = S + (wm * 64 + i * 32 + l31) * RQ;
-        ah[i] = __builtin_bit_cast(f16x8, row[2 * c + half]);
-        al[i] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+        for (int i = 0; i < 2; ++i) {
+          const u32x4* row = S + (wm * 64 + i * 32 + l31) * RQ;
+          ah[i] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+          al[i] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const u32x4* row = S + (BM + wn * 64 + jj * 32 + l31) * RQ;
+          bh[jj] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+          bl[jj] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
       }
+    } else {
+      f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];  // [k16 step][tile]
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const u32x4* row = S + (BM + wn * 64 + jj * 32 + l31) * RQ;
-        bh[jj] = __builtin_bit_cast(f16x8, row[2 * c + half]);
-        bl[jj] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4* row = S + (wm * 64 + i * 32 + l31) * RQ;
+          ah[c][i] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+          al[c][i] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const u32x4* row = S + (BM + wn * 64 + jj * 32 + l31) * RQ;
+          bh[c][jj] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+          bl[c][jj] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+        }
       }
+      if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][i], bh[c][jj], acc[i][jj], 0, 0, 0);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c][i], bl[c][jj], acc[i][jj], 0, 0, 0);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c][i], bh[c][jj], acc[i][jj], 0, 0, 0);
+      }
+      if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
     }
   };
   auto epilogue = [&](int ti) {
@@ -413,13 +453,14 @@ __global__ __launch_bounds__(512) void gemm_f16x3_persist_kernel(GemmSplitArgs p
   }
 }
 
-template <int EPI>
+template <int EPI, int VAR, int WM>
 static void launch_persist(const GemmSplitArgs& p, hipStream_t s) {
-  constexpr int smem = 2 * (256 + 128) * 9 * 16;
+  constexpr int BM = 64 * WM;
+  constexpr int smem = 2 * (BM + 128) * 9 * 16;
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_persist_kernel<EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_persist_kernel<EPI, VAR, WM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     int dev = 0;
     hipDeviceProp_t prop;
@@ -427,10 +468,10 @@ static void launch_persist(const GemmSplitArgs& p, hipStream_t s) {
       n_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  const int ntiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-  int grid = n_cu / 8 * 8;               // one workgroup per CU, a multiple of the 8 XCDs
+  const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
+  int grid = n_cu * (WM == 2 ? 2 : 1) / 8 * 8;  // one 8-wave or two 4-wave workgroups per CU, a multiple of the 8 XCDs
   if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
-  hipLaunchKernelGGL((gemm_f16x3_persist_kernel<EPI>), dim3(grid), dim3(512), smem, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_persist_kernel<EPI, VAR, WM>), dim3(grid), dim3(128 * WM), smem, s, p);
 }
 
 template <int EPI, int PF, int WM, int AL>
@@ -481,11 +522,15 @@ void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_sca
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
   static const int persist = env_int("FDMI_GEMM_PERSIST", 1);
   if (persist && dbg == 0 && (K / 32) % 2 == 0 && K >= 128) {
-    switch (epilogue) {
-      case EPI_BIAS: launch_persist<EPI_BIAS>(p, s); break;
-      case EPI_BIAS_GELU: launch_persist<EPI_BIAS_GELU>(p, s); break;
-      default: launch_persist<EPI_BIAS_RESID>(p, s); break;
-    }
+    static const int pbm = env_int("FDMI_GEMM_PBM", 256);  // rows per persistent workgroup: 256 (8 waves) | 128 (4 waves, 2 per CU)
+#define FD_PERSIST(W)                                                     \
+  switch (epilogue) {                                                     \
+    case EPI_BIAS: launch_persist<EPI_BIAS, 0, W>(p, s); break;           \
+    case EPI_BIAS_GELU: launch_persist<EPI_BIAS_GELU, 0, W>(p, s); break; \
+    default: launch_persist<EPI_BIAS_RESID, 0, W>(p, s); break;           \
+  }
+    if (pbm == 128) { FD_PERSIST(2) } else { FD_PERSIST(4) }
+#undef FD_PERSIST
     return;
   }
   if (dbg >= 1 && dbg <= 3) {
