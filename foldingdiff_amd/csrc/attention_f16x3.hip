@@ -173,17 +173,14 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
 
     // band row of R tile q, column l31:  m = (maxpos-1) - (LP-1) + LP*(qg-kt) + 32*wq + 32q + l31.
     // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos), so
-    // the index is clamped instead of predicated (keeps the loads unconditional).  The fetches run
-    // one band tile ahead of their use: L2 latency hides behind the MFMAs / the skew of the
-    // previous tile.
-    u32x4 enext[4];  // [hi c=0, hi c=1, lo c=0, lo c=1] of the next band tile
+    // the index is clamped instead of predicated (keeps the loads unconditional).  (Prefetching
+    // one band tile ahead was measured: no gain, and the extra registers push the kernel into spills.)
     auto load_band = [&](u32x4 (&e)[4], int q) {
       int m = (maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * q;
       m = m < 0 ? 0 : (m > 2 * (maxpos - 1) ? 2 * (maxpos - 1) : m);
       const u32x4* row = demb + (size_t)m * 8;  // 128-byte image: units 0-3 hi d0-31, 4-7 lo
       e[0] = row[half]; e[1] = row[2 + half]; e[2] = row[4 + half]; e[3] = row[6 + half];
     };
-    if constexpr (REL) load_band(enext, 0);
     // S^T tiles: rows = keys r0 + 32t + rowmap(r, half), cols = queries l0 + l31
     f32x16 sacc[T];
 #pragma unroll
@@ -218,11 +215,8 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
       const float R_SCALE = r_scale;  // 1 / (QS * table scale)
 #pragma unroll
       for (int q = 0; q <= T; ++q) {
-        // operands of band tile q were requested one tile earlier (tile 0: before the S^T MFMAs)
         u32x4 ecur[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ecur[u] = enext[u];
-        if (q < T) load_band(enext, q + 1);
+        load_band(ecur, q);
         f32x16 racc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) racc[r] = 0.f;
