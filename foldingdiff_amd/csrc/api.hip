@@ -818,6 +818,44 @@ int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, 
   return FD_OK;
 }
 
+int fd_nerf(int device_id, const float* feats, const int32_t* lens, int B, int L, int F, const int32_t* feat_idx,
+            int center, double* coords_out) {
+  if (!feats || !lens || !feat_idx || !coords_out || B < 1 || L < 1 || F < 3) return fail(FD_E_INVALID, "bad argument");
+  for (int i = 0; i < 9; ++i)
+    if (feat_idx[i] >= F || (i < 3 && feat_idx[i] < 0)) return fail(FD_E_INVALID, "feat_idx[%d]=%d (F=%d)", i, feat_idx[i], F);
+  if (int rc = check_lens(lens, B, L)) return rc;
+  HIP_TRY(hipSetDevice(device_id));
+  float* d_f = nullptr;
+  int* d_l = nullptr;
+  double* d_o = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_f, (void*)d_l, (void*)d_o})
+      if (p) (void)hipFree(p);
+  };
+#define N_TRY(expr)                                                          \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      cleanup();                                                             \
+      return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    }                                                                        \
+  } while (0)
+  const size_t nf = (size_t)B * L * F, no = (size_t)B * 3 * L * 3;
+  N_TRY(hipMalloc((void**)&d_f, nf * 4));
+  N_TRY(hipMalloc((void**)&d_l, (size_t)B * 4));
+  N_TRY(hipMalloc((void**)&d_o, no * 8));
+  N_TRY(hipMemcpy(d_f, feats, nf * 4, hipMemcpyHostToDevice));
+  N_TRY(hipMemcpy(d_l, lens, (size_t)B * 4, hipMemcpyHostToDevice));
+  NerfFeatures fx{feat_idx[0], feat_idx[1], feat_idx[2], feat_idx[3], feat_idx[4], feat_idx[5], feat_idx[6], feat_idx[7], feat_idx[8]};
+  launch_nerf(d_f, d_l, B, L, F, fx, center, d_o, nullptr);
+  N_TRY(hipGetLastError());
+  N_TRY(hipDeviceSynchronize());
+  N_TRY(hipMemcpy(coords_out, d_o, no * 8, hipMemcpyDeviceToHost));
+#undef N_TRY
+  cleanup();
+  return FD_OK;
+}
+
 int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, const float* W, const float* bias,
                  const float* resid, float* C, int M, int N, int K) {
   if (!A || !W || !bias || !C || M < 1 || N < 1 || K < 16 || K % 32) return fail(FD_E_INVALID, "bad argument");

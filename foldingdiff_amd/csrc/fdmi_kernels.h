@@ -94,6 +94,16 @@ struct UpdateArgs {
 };
 void launch_head_update(const UpdateArgs& a, hipStream_t s);
 
+// N1: NeRF internal -> Cartesian backbone coordinates, one lane per chain, fp64.
+// Feature column of each quantity in the [B][L][F] float32 array; -1 => the reference's constant.
+struct NerfFeatures {
+  int phi, psi, omega;                      // required
+  int ang_n_ca_c, ang_ca_c_n, ang_c_n_ca;   // "tau"/"N:CA:C", "CA:C:1N", "C:1N:1CA"
+  int len_c_n, len_n_ca, len_ca_c;          // "0C:1N", "N:CA", "CA:C"
+};
+void launch_nerf(const float* feats, const int* lens, int B, int L, int F, const NerfFeatures& fx, int center,
+                 double* out /* [B][3L][3] */, hipStream_t s);
+
 // *t_dev -= 1  (last node of the per-step graph)
 void launch_step_advance(int* t_dev, hipStream_t s);
 

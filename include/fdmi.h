@@ -157,6 +157,18 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
 int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, int B, int L, void* out_dev,
                          void* hip_stream);
 
+/* ---- post-processing: angles -> backbone coordinates ----
+ * Replaces NERFBuilder.cartesian_coords / .centered_cartesian_coords (foldingdiff/nerf.py:78-129,
+ * place_dihedral :145-204) as create_new_chain_nerf calls them (foldingdiff/angles_and_coords.py:112-184).
+ *   feats     float32 [B][L][F] sampled features (host), lens int32[B] residues per chain
+ *   feat_idx  int32[9]: column of phi, psi, omega, N:CA:C ("tau"), CA:C:1N, C:1N:1CA, 0C:1N, N:CA, CA:C;
+ *             -1 for an angle / length that is not a feature => the reference's constant
+ *             (109, 115, 121 degrees; 1.34, 1.46, 1.54 Angstrom); the three dihedrals are required
+ *   center    subtract the mean atom position of each chain (centered_cartesian_coords)
+ *   coords_out float64 [B][3*L][3]: N, CA, C of each residue; rows of residues >= lens[b] are 0 */
+int fd_nerf(int device_id, const float* feats, const int32_t* lens, int B, int L, int F, const int32_t* feat_idx,
+            int center, double* coords_out);
+
 /* ---- test hook ----
  * One token GEMM  C[M,N] = A[M,K] W[N,K]^T + bias (+GELU | +resid) through the production
  * kernels of the given precision (epilogue: 0 bias, 1 bias+GELU, 2 bias+residual).  Host buffers,

@@ -28,6 +28,7 @@ Fixtures written (all float32 unless noted):
   ref_abs_model.npz   reference BertForDiffusionBase(absolute): weights, x, t, mask, eps
   ref_abs_traj.npz    reference p_sample_loop on that model: T=10 trajectory
   ref_abs_sample.npz  reference sampling.sample() end to end (with mean offset)
+  ref_nerf.npz        NERFBuilder coordinates (raw + centered) for the three angle feature sets, L in {1,2,37,128}
   c1_relkey.npz       BASELINE config C1 (mini relative_key model, L=64, T=10, B=4):
                       oracle model + reference sampler trajectory, fp32 and fp64
 """
@@ -268,6 +269,46 @@ def main():
     np.savez_compressed(os.path.join(HERE, "c1_relkey.npz"), weight_seed=0, weight_sha256=digest, x0=x01.numpy(),
                         lens=np.array(lens1), step_noise=sn1.numpy(), traj=traj1.numpy(), T=T1,
                         lens_ragged=np.array(lens_r), **fwd)
+    # ------------------------------------------------ NeRF: reference NERFBuilder
+    from foldingdiff import nerf as ref_nerf_mod
+    from oracle import ref_nerf
+    rng = np.random.default_rng(20240924)
+    nerf_out = {}
+    names9 = ["0C:1N", "N:CA", "CA:C", "phi", "psi", "omega", "tau", "CA:C:1N", "C:1N:1CA"]  # "canonical"
+    for tag, names in (("full", names9[3:]), ("minimal", names9[3:7]), ("canonical", names9)):
+        for Ln in (1, 2, 37, 128):
+            cols = {}
+            for nme in names:
+                if nme in ("phi", "psi", "omega"):
+                    cols[nme] = rng.uniform(-np.pi, np.pi, Ln).astype(np.float32)
+                elif ":" in nme and nme.count(":") == 1:
+                    cols[nme] = rng.uniform(1.3, 1.6, Ln).astype(np.float32)
+                else:
+                    cols[nme] = rng.uniform(1.8, 2.2, Ln).astype(np.float32)
+            # the keyword mapping of create_new_chain_nerf (angles_and_coords.py:142-173)
+            kw = dict(phi_dihedrals=cols["phi"], psi_dihedrals=cols["psi"], omega_dihedrals=cols["omega"])
+            if "tau" in cols: kw["bond_angle_ca_c"] = cols["tau"]
+            if "CA:C:1N" in cols: kw["bond_angle_c_n"] = cols["CA:C:1N"]
+            if "C:1N:1CA" in cols: kw["bond_angle_n_ca"] = cols["C:1N:1CA"]
+            if "0C:1N" in cols: kw["bond_len_c_n"] = cols["0C:1N"]
+            if "N:CA" in cols: kw["bond_len_n_ca"] = cols["N:CA"]
+            if "CA:C" in cols: kw["bond_len_ca_c"] = cols["CA:C"]
+            if Ln == 1:  # NERFBuilder squeezes length-1 arrays to 0-d; the seed atoms are the whole answer
+                raw = np.array([ref_nerf_mod.N_INIT, ref_nerf_mod.CA_INIT, ref_nerf_mod.C_INIT])
+                cen = raw - raw.mean(axis=0)
+            else:
+                bld = ref_nerf_mod.NERFBuilder(**kw)
+                raw, cen = np.asarray(bld.cartesian_coords), np.asarray(bld.centered_cartesian_coords)
+                mine = ref_nerf.build(cols["phi"], cols["psi"], cols["omega"], cols.get("tau"), cols.get("CA:C:1N"),
+                                      cols.get("C:1N:1CA"), center=False,
+                                      len_c_n=cols.get("0C:1N"), len_n_ca=cols.get("N:CA"), len_ca_c=cols.get("CA:C"))
+                assert np.array_equal(mine, raw), (tag, Ln, np.abs(mine - raw).max())
+            feats = np.stack([cols[n] for n in names], axis=1)
+            nerf_out[f"{tag}_{Ln}_feats"] = feats
+            nerf_out[f"{tag}_{Ln}_raw"] = raw
+            nerf_out[f"{tag}_{Ln}_centered"] = cen
+    nerf_out["names_full"] = np.array(names9[3:]); nerf_out["names_minimal"] = np.array(names9[3:7]); nerf_out["names_canonical"] = np.array(names9)
+    np.savez_compressed(os.path.join(HERE, "ref_nerf.npz"), **nerf_out)
     print("weights sha256", digest)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -155,3 +155,19 @@ def test_masked_tail_invariance_and_batch_order():
         assert torch.allclose(out[i, :n], out2[i, :n], rtol=1e-3, atol=1e-6)
     rev = m(torch.flip(x, (0,)), t, attention_mask=torch.flip(mask, (0,)))
     assert torch.allclose(torch.flip(out, (0,)), rev, rtol=1e-3, atol=1e-6)
+
+
+def test_nerf_oracle_vs_reference_golden():
+    """oracle/ref_nerf.py reproduces the reference's NERFBuilder bit for bit (fixtures: make_golden.py)."""
+    from oracle import ref_nerf
+    g = golden("ref_nerf.npz")
+    for tag in ("full", "minimal", "canonical"):
+        names = [str(n) for n in g[f"names_{tag}"]]
+        for Ln in (1, 2, 37, 128):
+            f = g[f"{tag}_{Ln}_feats"]
+            col = {n: f[:, i] for i, n in enumerate(names)}
+            for center, key in ((False, "raw"), (True, "centered")):
+                got = ref_nerf.build(col["phi"], col["psi"], col["omega"], col.get("tau"), col.get("CA:C:1N"),
+                                     col.get("C:1N:1CA"), center=center, len_c_n=col.get("0C:1N"),
+                                     len_n_ca=col.get("N:CA"), len_ca_c=col.get("CA:C"))
+                assert np.array_equal(got, g[f"{tag}_{Ln}_{key}"]), (tag, Ln, key)
