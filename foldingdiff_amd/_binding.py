@@ -57,6 +57,7 @@ _SIGNATURES = {
     "fd_philox_normal_dev": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P]),
     "fd_nerf": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "fd_test_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "fd_test_gemm_ln": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_int]),
     "fd_test_gemm_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "fd_profile_every": (C.c_int, [_P, C.c_int]),
     "fd_profile_reset": (C.c_int, [_P]),

@@ -338,7 +338,8 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
   const fd_config& c = m->cfg;
   Workspace& w = m->ws;
   const int B = w.B, L = w.L, M = B * L, d = c.d_model, ff = c.d_ff, F = c.n_features;
-  const bool fuse_ln = m->fuse_ln && m->precision == FD_PREC_F32;
+  const bool fuse_ln = m->fuse_ln != 0;
+  const bool split = m->precision == FD_PREC_F16X3;
   PROF(KC_EMBED, launch_embed(w.x, m->w_in, m->b_in, m->pos_emb, m->emb_g, m->emb_b, c.ln_eps, m->time_table, w.t_dev,
                               w.h, B, L, F, d, s));
   for (int li = 0; li < c.n_layers; ++li) {
@@ -351,7 +352,8 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
     if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by the fp32 kernel (max 128)", L);
     bool fused = false;
     if (fuse_ln)
-      PROF(KC_GEMM_OUT, fused = launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
+      PROF(KC_GEMM_OUT, fused = split ? launch_gemm_f16x3_ln(w.ctx, lw.wo_s.p, lw.wo_s.scale, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s)
+                                       : launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
     if (!fused) {
       if (fuse_ln && mode.profile) {  // the attempted launch recorded an empty bracket; drop it
         PendingEvent p = m->pending.back();
@@ -365,7 +367,8 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
     PROF(KC_GEMM_UP, gemm(m, EPI_BIAS_GELU, w.a, lw.wi, lw.wi_s, lw.bi, nullptr, w.g, M, ff, d, s));
     fused = false;
     if (fuse_ln)
-      PROF(KC_GEMM_DOWN, fused = launch_gemm_f32_ln(w.g, lw.wd, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s));
+      PROF(KC_GEMM_DOWN, fused = split ? launch_gemm_f16x3_ln(w.g, lw.wd_s.p, lw.wd_s.scale, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s)
+                                        : launch_gemm_f32_ln(w.g, lw.wd, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s));
     if (!fused) {
       if (fuse_ln && mode.profile) {
         PendingEvent p = m->pending.back();
@@ -907,6 +910,68 @@ int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, con
 #undef T_TRY
   cleanup();
   return rc;
+}
+
+int fd_test_gemm_ln(int device_id, int precision, int use_fused, const float* A, const float* W, const float* bias,
+                    const float* resid, const float* gamma, const float* beta, float eps, float* C, int M, int N,
+                    int K) {
+  if (!A || !W || !bias || !resid || !gamma || !beta || !C || M < 1 || N < 1 || K < 32 || K % 32)
+    return fail(FD_E_INVALID, "bad argument");
+  if (precision != FD_PREC_F32 && precision != FD_PREC_F16X3) return fail(FD_E_INVALID, "precision %d", precision);
+  HIP_TRY(hipSetDevice(device_id));
+  std::vector<void*> bufs;
+  auto cleanup = [&]() {
+    for (void* p : bufs) (void)hipFree(p);
+  };
+#define T_TRY(expr)                                                          \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      cleanup();                                                             \
+      return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    }                                                                        \
+  } while (0)
+  auto up = [&](const void* host, size_t bytes, void** dev) -> hipError_t {
+    hipError_t e = hipMalloc(dev, bytes);
+    if (e != hipSuccess) return e;
+    bufs.push_back(*dev);
+    return host ? hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  float *dA, *dW, *db, *dr, *dg, *dbt, *dT, *dC;
+  T_TRY(up(A, (size_t)M * K * 4, (void**)&dA));
+  T_TRY(up(W, (size_t)N * K * 4, (void**)&dW));
+  T_TRY(up(bias, (size_t)N * 4, (void**)&db));
+  T_TRY(up(resid, (size_t)M * N * 4, (void**)&dr));
+  T_TRY(up(gamma, (size_t)N * 4, (void**)&dg));
+  T_TRY(up(beta, (size_t)N * 4, (void**)&dbt));
+  T_TRY(up(nullptr, (size_t)M * N * 4, (void**)&dT));
+  T_TRY(up(nullptr, (size_t)M * N * 4, (void**)&dC));
+  void* dWp = nullptr;
+  float wscale = 1.f;
+  if (precision == FD_PREC_F16X3) {
+    std::vector<uint16_t> img;
+    pack_split_weight(W, N, K, &img, &wscale);
+    T_TRY(up(img.data(), img.size() * 2, &dWp));
+  }
+  if (use_fused) {
+    const bool ok = precision == FD_PREC_F16X3
+                        ? launch_gemm_f16x3_ln(dA, dWp, wscale, db, dr, dg, dbt, eps, dC, M, N, K, nullptr)
+                        : launch_gemm_f32_ln(dA, dW, db, dr, dg, dbt, eps, dC, M, N, K, nullptr);
+    if (!ok) {
+      cleanup();
+      return fail(FD_E_UNSUPPORTED, "no LN-fused GEMM for N=%d K=%d in this precision", N, K);
+    }
+  } else {
+    if (precision == FD_PREC_F16X3) launch_gemm_f16x3(EPI_BIAS_RESID, dA, dWp, wscale, db, dr, dT, M, N, K, nullptr);
+    else launch_gemm_f32(EPI_BIAS_RESID, dA, dW, db, dr, dT, M, N, K, nullptr);
+    launch_layernorm(dT, dg, dbt, eps, dC, M, N, nullptr);
+  }
+  T_TRY(hipGetLastError());
+  T_TRY(hipDeviceSynchronize());
+  T_TRY(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+#undef T_TRY
+  cleanup();
+  return FD_OK;
 }
 
 int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int reps, double* ms_per_launch) {

@@ -31,6 +31,11 @@ void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_sca
 bool launch_gemm_f32_ln(const float* A, const float* W, const float* bias, const float* resid, const float* gamma,
                         const float* beta, float eps, float* C, int M, int N, int K, hipStream_t s);
 
+// The same fusion in fp16x3 split arithmetic (N == 384, K % 64 == 0, K >= 128); false otherwise.
+bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const float* bias, const float* resid,
+                          const float* gamma, const float* beta, float eps, float* C, int M, int N, int K,
+                          hipStream_t s);
+
 // y[r,:] = LN(x[r,:]) * gamma + beta, rows of length d (d <= 1024), one wave per row.
 void launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int d,
                       hipStream_t s);

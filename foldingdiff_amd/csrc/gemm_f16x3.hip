@@ -474,6 +474,288 @@ static void launch_persist(const GemmSplitArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_f16x3_persist_kernel<EPI, VAR, WM>), dim3(grid), dim3(128 * WM), smem, s, p);
 }
 
+// ---------------------------------------------------------------------------------------------
+// GEMM + bias + residual + LayerNorm over full rows (BertSelfOutput / BertOutput, transformers
+// 4.11.3: LN(dense(x) + input)), N == 384 == the whole row in one workgroup.
+// Same persistent (tile, k-tile) stream as above with a 128 x 384 block: 8 waves as 2 (M) x 4 (N),
+// each 64 x 96 (2 x 3 MFMA tiles, 96 accumulator registers, 18 MFMAs per 10 fragment fetches).
+// The epilogue finishes v = acc + bias + resid in registers, reduces each row's 96 columns inside
+// the wave (DPP butterflies over the 32 lanes that share a row), combines the four N-waves through a
+// 2 KB LDS scratch, and repeats that for the centred squares (two-pass variance, as
+// rowwise.hip:row_layernorm): the pre-LN tensor never goes to HBM and the standalone LayerNorm
+// launch (201 MB of traffic per call at M = 65536) disappears.
+struct StreamNo { static constexpr bool value = false; };
+struct StreamYes { static constexpr bool value = true; };
+
+struct GemmLnArgs {
+  const float* A;
+  const u32x4* Wp;
+  const float* bias;
+  const float* resid;
+  const float* gamma;
+  const float* beta;
+  float* C;
+  int M, K;
+  float a_scale, out_scale, eps;
+};
+
+// sum over the 32 lanes of this lane's half-wave (result in every lane)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#define FD_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  FD_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+  FD_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+  FD_DPP_ADD(0x141);  // row_half_mirror: lanes of a quad hold equal sums, so i <-> 7-i adds the other quad
+  FD_DPP_ADD(0x140);  // row_mirror: i <-> 15-i adds the other 8 lanes
+#undef FD_DPP_ADD
+  return v + __shfl_xor(v, 16);
+}
+
+__global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
+  constexpr int BM = 128, BN = 384, BK = 32, RQ = 9, NTHR = 512, NT = 3;
+  constexpr int WU = BN * 8 / NTHR;  // 6 W image units (16 B) per thread per k-tile
+  constexpr int STAGE = (BM + BN) * RQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
+  float* red = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][128 rows][4 N-waves]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntiles = (p.M + BM - 1) / BM;
+  const int K = p.K, nk = K / BK;
+  const int first = blockIdx.x, stride = gridDim.x;
+  const int cnt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  if (cnt == 0) return;
+  const int G = cnt * nk;
+
+  const int arow = tid >> 2, au = tid & 3;   // A: one (row, 8-float octet) per thread
+  const int wrow = tid >> 3, wu = tid & 7;   // W image: unit wu of rows wrow + 64 i
+
+  f32x16 acc[2][NT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+  };
+  zero_acc();
+
+  float4 ra0[2], ra1[2];
+  u32x4 rw0[WU], rw1[WU];
+  auto gload = [&](float4 (&ra)[2], u32x4 (&rw)[WU], int g) {
+    g = g < G ? g : G - 1;
+    const int ti = g / nk, kt = g - ti * nk;
+    const int m0 = (first + ti * stride) * BM;
+    const int r1 = m0 + arow < p.M ? m0 + arow : p.M - 1;
+    const float* a1 = p.A + (size_t)r1 * K + kt * BK + 8 * au;
+    ra[0] = *reinterpret_cast<const float4*>(a1);
+    ra[1] = *reinterpret_cast<const float4*>(a1 + 4);
+    const u32x4* w = p.Wp + ((size_t)wrow * nk + kt) * 8 + wu;
+#pragma unroll
+    for (int i = 0; i < WU; ++i) rw[i] = w[(size_t)i * 64 * nk * 8];
+  };
+  auto lstore = [&](const float4 (&ra)[2], const u32x4 (&rw)[WU], int buf) {
+    u32x4* S = smem + buf * STAGE;
+    u32x4 h0, l0;
+    split8(ra[0], ra[1], p.a_scale, h0, l0);
+    u32x4* row = S + arow * RQ;
+    row[au] = h0;
+    row[4 + au] = l0;
+#pragma unroll
+    for (int i = 0; i < WU; ++i) S[(BM + wrow + 64 * i) * RQ + wu] = rw[i];
+  };
+  auto compute = [&](int buf) {
+    const u32x4* S = smem + buf * STAGE;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4* row = S + (wm * 64 + i * 32 + l31) * RQ;
+        ah[i] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+        al[i] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj) {
+        const u32x4* row = S + (BM + wn * 96 + jj * 32 + l31) * RQ;
+        bh[jj] = __builtin_bit_cast(f16x8, row[2 * c + half]);
+        bl[jj] = __builtin_bit_cast(f16x8, row[4 + 2 * c + half]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+    }
+  };
+
+  // row statistic of the workgroup: per-(i, r) partial sums of this wave -> LDS -> sum over the 4 N-waves.
+  // LDS addresses are one per-lane base (re-derived per call, so that nothing is hoisted out of the tile
+  // loop and spilled) + compile-time offsets.
+  auto block_row_sum = [&](float (&s)[2][16], float* scratch) {
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[i][r] = half_wave_sum(s[i][r]);
+        mine = (l31 == i * 16 + r) ? s[i][r] : mine;
+      }
+    int rbase = (wm * 64 + 4 * half) * 4;  // float index of tile row (wm*64 + 4*half), N-wave 0
+    asm volatile("" : "+v"(rbase));
+    {
+      const int i = l31 >> 4, r = l31 & 15;
+      scratch[rbase + (i * 32 + (r & 3) + 8 * (r >> 2)) * 4 + wn] = mine;
+    }
+    __syncthreads();
+    const float* rd = scratch + rbase;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 q = *reinterpret_cast<const float4*>(rd + (i * 32 + (r & 3) + 8 * (r >> 2)) * 4);
+        s[i][r] = (q.x + q.y) + (q.z + q.w);
+      }
+  };
+
+  // Register budget (256 per lane at 2 waves/SIMD): 96 accumulators + ONE prefetch set (32) stay live
+  // across the epilogue; the second set is re-issued after it (see the stream loop below).
+  // Addresses are (wave-uniform row base in SGPRs) + (one per-lane offset): a per-row VGPR address
+  // pair would cost 64 registers and spill.
+  auto epilogue = [&](int ti) {   // M % 128 == 0 (host guarantees): every tile is full
+    const int row0 = __builtin_amdgcn_readfirstlane((first + ti * stride) * BM + wm * 64);
+    int loff = 4 * half * BN + wn * 96 + l31;   // lane part of every element offset
+    asm volatile("" : "+v"(loff));               // re-derived per tile: nothing address-like is hoisted out of the tile loop
+    const float* rbase = p.resid + (size_t)row0 * BN;
+    float* cbase = p.C + (size_t)row0 * BN;
+    float s[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
+    // residual: 6 batches (jj, i) of 16 loads, two batches in flight
+    float rv[2][16];
+    float bz[NT];
+#pragma unroll
+    for (int jj = 0; jj < NT; ++jj) bz[jj] = p.bias[wn * 96 + jj * 32 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[0][r] = (rbase + ((r & 3) + 8 * (r >> 2)) * BN)[loff];
+#pragma unroll
+    for (int b = 0; b < 2 * NT; ++b) {
+      const int jj = b >> 1, i = b & 1;
+      if (b + 1 < 2 * NT) {
+        const int jn = (b + 1) >> 1, in = (b + 1) & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[(b + 1) & 1][r] = (rbase + (in * 32 + (r & 3) + 8 * (r >> 2)) * BN)[loff + jn * 32];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[i][jj][r] * p.out_scale + bz[jj] + rv[b & 1][r];
+        acc[i][jj][r] = v;
+        s[i][r] += v;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the batches apart (register pressure)
+    }
+    float gm[NT], bt[NT];  // fetched here (the residual registers are free again), long before the stores
+#pragma unroll
+    for (int jj = 0; jj < NT; ++jj) {
+      gm[jj] = p.gamma[wn * 96 + jj * 32 + l31];
+      bt[jj] = p.beta[wn * 96 + jj * 32 + l31];
+    }
+    block_row_sum(s, red);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float mean = s[i][r] * (1.0f / BN);
+        float t = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj) {
+          const float dl = acc[i][jj][r] - mean;
+          acc[i][jj][r] = dl;
+          t += dl * dl;
+        }
+        s[i][r] = t;
+      }
+    block_row_sum(s, red + BM * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[i][r] = 1.0f / sqrtf(s[i][r] * (1.0f / BN) + p.eps);
+#pragma unroll
+    for (int jj = 0; jj < NT; ++jj) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          (cbase + (i * 32 + (r & 3) + 8 * (r >> 2)) * BN)[loff + jj * 32] = acc[i][jj][r] * s[i][r] * gm[jj] + bt[jj];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // stream positions: even g -> LDS buffer 0 / register set 1, odd g -> buffer 1 / set 0
+  auto pair = [&](int g, auto last) {
+    compute(0);
+    lstore(ra0, rw0, 1);
+    gload(ra0, rw0, g + 3);
+    __syncthreads();
+    compute(1);
+    lstore(ra1, rw1, 0);  // position g+2: for the last k-pair of a tile this is already the NEXT tile
+    if constexpr (!decltype(last)::value) gload(ra1, rw1, g + 4);
+    __syncthreads();
+  };
+  gload(ra1, rw1, 0);
+  lstore(ra1, rw1, 0);
+  gload(ra0, rw0, 1);
+  gload(ra1, rw1, 2);
+  __syncthreads();
+  const int npairs = nk / 2;  // >= 2 (host guarantees)
+  for (int ti = 0; ti < cnt; ++ti) {
+    const int g0 = ti * nk;
+    pair(g0, StreamNo{});
+    for (int pi = 1; pi < npairs - 1; ++pi) pair(g0 + 2 * pi, StreamNo{});
+    pair(g0 + nk - 2, StreamYes{});   // the load of stream position g0+nk+2 is issued after the epilogue
+    epilogue(ti);
+    gload(ra1, rw1, g0 + nk + 2);
+    zero_acc();
+  }
+}
+
+bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const float* bias, const float* resid,
+                          const float* gamma, const float* beta, float eps, float* C, int M, int N, int K,
+                          hipStream_t s) {
+  if (N != 384 || K % 64 != 0 || K < 128 || M % 128 != 0) return false;
+  constexpr int smem = 2 * (128 + 384) * 9 * 16 + 2 * 128 * 4 * 4;  // 151,552 B
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const float a_scale = 16.0f;
+  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps};
+  const int ntiles = (M + 127) / 128;
+  const int grid = ntiles < n_cu ? ntiles : n_cu;
+  hipLaunchKernelGGL(gemm_f16x3_ln_kernel, dim3(grid), dim3(512), smem, s, p);
+  return true;
+}
+
 template <int EPI, int PF, int WM, int AL>
 static void launch_one(const GemmSplitArgs& p, hipStream_t s) {
   constexpr int BM = 64 * WM;

@@ -176,6 +176,13 @@ int fd_nerf(int device_id, const float* feats, const int32_t* lens, int B, int L
 int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, const float* W, const float* bias,
                  const float* resid, float* C, int M, int N, int K);
 
+/* C = LayerNorm(A W^T + bias + resid) * gamma + beta over full rows (HF BertSelfOutput / BertOutput,
+ * reached from modelling.py:473-480).  use_fused != 0 asks for the LN-fused GEMM kernel of that precision
+ * (FD_E_UNSUPPORTED if the shape has no fused instantiation); 0 runs GEMM(+residual) then the LayerNorm kernel. */
+int fd_test_gemm_ln(int device_id, int precision, int use_fused, const float* A, const float* W, const float* bias,
+                    const float* resid, const float* gamma, const float* beta, float eps, float* C, int M, int N,
+                    int K);
+
 /* Average launch time (ms) of the bias-epilogue token GEMM of the given precision on pseudo-random
  * operands, `reps` back-to-back launches bracketed by hipEvents (kernel micro-benchmark / ablations). */
 int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int reps, double* ms_per_launch);
