@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=100)
     ap.add_argument("--no-history", action="store_true", help="do not keep the [T,B,L,F] history in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse-ln", type=int, default=0)
+    ap.add_argument("--fuse-ln", type=int, default=-1, help="-1 auto (fused with f16x3), 0 off, 1 on")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM arithmetic (default: library default)")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the extra single pass in exact-fp32 MFMA mode that is reported next to the headline (N=1 only)")
@@ -249,7 +249,8 @@ def main():
                                f"L={L}, T={T}, batch {B}/GPU, synthetic HF-init weights, Philox noise, "
                                f"history {'off' if args.no_history else 'in HBM'}",
                    "global_batch": B * world, "seq_len": L, "timesteps": T, "parallelism": f"batch-shard x{world}",
-                   "fuse_ln": args.fuse_ln, "gemm_precision": model.precision},
+                   "fuse_ln": (args.fuse_ln if args.fuse_ln >= 0 else int(model.precision == "f16x3")),
+                   "gemm_precision": model.precision},
         "whole_step": {"algorithmic_tflops": value * flop_per_backbone / 1e12 / world,
                        "frac_of_mfma_peak": value * flop_per_backbone / 1e12 / world / pinfo["peak"],
                        "ms_per_timestep": elapsed / args.steps / T * 1e3},

@@ -197,13 +197,11 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
         sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
       }
     }
-    // Scores are carried in the log2 domain, pre-divided by sqrt(head size): one multiply here (and
-    // one on the band values below) replaces the separate /sqrt(32) and the x*log2(e) inside exp().
+    // Scores stay RAW MFMA sums u (scaled by QS*KS): the factor log2(e) / sqrt(head size) / (QS*KS)
+    // that takes them to the log2 domain is applied inside the exponent fma of the softmax, and the
+    // band values are brought to the same raw scale by the (power-of-two, exact) ratio of the scales
+    // inside the accumulate fma -- no separate scaling pass over scores or band tiles.
     constexpr float S_SCALE = kLog2eOverSqrtD / (QS * KS);
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[t][r] *= S_SCALE;
     if constexpr (REL) {
       // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31 (band origin: this
       // wave's row block).  S^T tile t element (key kl, query ql)
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
       // band row of R tile q, column l31:  m = (maxpos-1) - (LP-1) + LP*(qg-kt) + 32*wq + 32q + l31.
       // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos), so
       // the index is clamped instead of predicated (keeps the loads unconditional).
-      const float R_SCALE = r_scale;  // 1 / (QS * table scale)
+      const float R_RATIO = r_scale;  // KS / table scale: band sums -> the raw scale of the scores
 #pragma unroll
       for (int q = 0; q <= T; ++q) {
         u32x4 ecur[4];
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
           racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[c], eh, racc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r] * R_SCALE;
+        for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -247,14 +245,14 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            sacc[T - 1 - q][r] += (l31 <= kl) ? gth[r] : 0.f;
+            sacc[T - 1 - q][r] = __builtin_fmaf((l31 <= kl) ? gth[r] : 0.f, R_RATIO, sacc[T - 1 - q][r]);
           }
         }
         if (q > 0) {  // high tile of S^T tile t = T-q
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            sacc[T - q][r] += (l31 > kl) ? gth[r] : 0.f;
+            sacc[T - q][r] = __builtin_fmaf((l31 > kl) ? gth[r] : 0.f, R_RATIO, sacc[T - q][r]);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -276,26 +274,29 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
         for (int r = 0; r < 16; ++r) {
           const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
           float sc = sacc[t][r];
-          if (key >= len) sc += kMaskLog2;   // (1 - mask) * -10000   (modelling.py:452)
+          if (key >= len) sc += kMaskLog2 / S_SCALE;   // (1 - mask) * -10000   (modelling.py:452), raw scale
           if (key >= L) sc = -INFINITY;      // tile padding: not a key at all
           sacc[t][r] = sc;
           mt = fmaxf(mt, sc);
         }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp2_neg(m_run - m_new);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
+    const float m_new = fmaxf(m_run, mt);                    // running maximum, raw scale
+    const float alpha = exp2_neg((m_run - m_new) * S_SCALE);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
+    // p' = PS * 2^((u - m) * S_SCALE): the fp16-split scale PS = 2^10 rides in the exponent
+    const float nm = __builtin_fmaf(-m_new, S_SCALE, 10.0f);
+    static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pexp = exp2_neg(sacc[t][r] - m_new);
+        const float pexp = exp2_neg(__builtin_fmaf(sacc[t][r], S_SCALE, nm));
         sacc[t][r] = pexp;
         psum += pexp;
       }
     psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;
+    l_run = l_run * alpha + psum;   // carries the factor PS
     m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
         f16x8 ph, pl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xs = sacc[t][8 * c + j] * PS;  // unnormalised probabilities (<= 1), scaled for the fp16 split
+          const float xs = sacc[t][8 * c + j];  // PS * unnormalised probability (<= PS): ready for the fp16 split
           const _Float16 hv = (_Float16)xs;
           ph[j] = hv;
           pl[j] = (_Float16)(xs - (float)hv);
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
   // quad, four consecutive d = 8*(r>>2) + 4*half + (r&3)
   const int l = l0 + l31;
   if (l < L) {
-    const float onorm = 1.0f / (PS * VS * l_run);
+    const float onorm = 1.0f / (VS * l_run);  // l_run and the accumulator both carry PS
     float* dst = ctx + ((size_t)b * L + l) * d + h * 32 + 4 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -368,7 +369,7 @@ bool launch_attention_f16x3(const float* qkv, const void* dist_emb_split, float 
   if (L < 1) return false;
   const int T = L > 128 ? 4 : (L + 31) / 32;  // long sequences: 128-key tiles x 128-query groups, online softmax
   const bool rel = dist_emb_split != nullptr;
-  const float r_scale = a16::kLog2eOverSqrtD / (a16::QS * table_scale);  // band values land in the same log2 / sqrt(d) domain as the scores
+  const float r_scale = a16::KS / table_scale;  // band sums (scaled QS * table_scale) -> raw score scale QS * KS; a power of two
 #define FD_ATTN16_CASE(TT)                                                                              \
   case TT:                                                                                              \
     if (rel) a16::launch_t<TT, true>(qkv, dist_emb_split, r_scale, lens, ctx, B, L, H, maxpos, s);      \

@@ -52,7 +52,33 @@ __device__ __forceinline__ int xcd_remap16(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-__device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(x) as the (odd degree-13) / (even degree-8) rational minimax on [-4, 4] (the single-precision
+// form used by Eigen / XLA; |x| > 4 is +-1 in fp32): max abs error 4.5e-7 vs float64 erf (checked in
+// tests/test_host.py on 3M points) -- the same class as libm's erff -- at 18 branch-free VALU ops per
+// GELU instead of erff's two divergent branches (the GELU epilogue runs 50M times per FFN-up launch).
+__device__ __forceinline__ float erf_rational(float x) {
+  x = __builtin_fminf(__builtin_fmaxf(x, -4.0f), 4.0f);
+  const float x2 = x * x;
+  float p = -2.72614225801306e-10f;
+  p = __builtin_fmaf(p, x2, 2.77068142495902e-08f);
+  p = __builtin_fmaf(p, x2, -2.10102402082508e-06f);
+  p = __builtin_fmaf(p, x2, -5.69250639462346e-05f);
+  p = __builtin_fmaf(p, x2, -7.34990630326855e-04f);
+  p = __builtin_fmaf(p, x2, -2.95459980854025e-03f);
+  p = __builtin_fmaf(p, x2, -1.60960333262415e-02f);
+  float q = -1.45660718464996e-05f;
+  q = __builtin_fmaf(q, x2, -2.13374055278905e-04f);
+  q = __builtin_fmaf(q, x2, -1.68282697438203e-03f);
+  q = __builtin_fmaf(q, x2, -7.37332916720468e-03f);
+  q = __builtin_fmaf(q, x2, -1.42647390514189e-02f);
+  return (p * x) * __builtin_amdgcn_rcpf(q);
+}
+
+// exact-erf GELU (HF "gelu", modelling.py:195-196): 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf16(float x) {
+  const float h = 0.5f * x;
+  return __builtin_fmaf(h, erf_rational(x * 0.70710678118654752440f), h);
+}
 
 // split 8 fp32 values (two float4) into hi / lo fp16 octets; pure register code (vector
 // element inserts + bitcasts: nothing for the compiler to demote to scratch or LDS)
@@ -481,9 +507,11 @@ static void launch_persist(const GemmSplitArgs& p, hipStream_t s) {
 // each 64 x 96 (2 x 3 MFMA tiles, 96 accumulator registers, 18 MFMAs per 10 fragment fetches).
 // The epilogue finishes v = acc + bias + resid in registers, reduces each row's 96 columns inside
 // the wave (DPP butterflies over the 32 lanes that share a row), combines the four N-waves through a
-// 2 KB LDS scratch, and repeats that for the centred squares (two-pass variance, as
+// small LDS scratch, and repeats that for the centred squares (two-pass variance, as
 // rowwise.hip:row_layernorm): the pre-LN tensor never goes to HBM and the standalone LayerNorm
 // launch (201 MB of traffic per call at M = 65536) disappears.
+static int env_int(const char* name, int dflt);
+
 struct StreamNo { static constexpr bool value = false; };
 struct StreamYes { static constexpr bool value = true; };
 
@@ -497,18 +525,22 @@ struct GemmLnArgs {
   float* C;
   int M, K;
   float a_scale, out_scale, eps;
+  int stagger;  // experiment: every other workgroup of an XCD starts `stagger` x ~3.4 us late (de-phases the HBM-heavy epilogues)
 };
 
-// sum over the 32 lanes of this lane's half-wave (result in every lane)
-__device__ __forceinline__ float half_wave_sum(float v) {
-#define FD_DPP_ADD(ctrl) \
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-  FD_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
-  FD_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
-  FD_DPP_ADD(0x141);  // row_half_mirror: lanes of a quad hold equal sums, so i <-> 7-i adds the other quad
-  FD_DPP_ADD(0x140);  // row_mirror: i <-> 15-i adds the other 8 lanes
+// Sum over the 32 lanes of this lane's half-wave, DPP only (no LDS round trip).  The result is
+// valid in the UPPER 16 lanes of each half (lanes 16-31 and 48-63): row_bcast15 adds the lower
+// row's total into the upper row only.
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+#define FD_DPP_ADD(ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  FD_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  FD_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  FD_DPP_ADD(0x141, 0xf);  // row_half_mirror: lanes of a quad hold equal sums, so i <-> 7-i adds the other quad
+  FD_DPP_ADD(0x140, 0xf);  // row_mirror: i <-> 15-i adds the other 8 lanes
+  FD_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3: + the total of the 16 lanes below
 #undef FD_DPP_ADD
-  return v + __shfl_xor(v, 16);
+  return v;
 }
 
 __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
@@ -517,7 +549,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   constexpr int STAGE = (BM + BN) * RQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
-  float* red = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][128 rows][4 N-waves]
+  float* red = reinterpret_cast<float*>(smem + 2 * STAGE);  // 2 passes x (part[128][4] + tot[128])
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
@@ -528,6 +560,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   const int cnt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
   if (cnt == 0) return;
   const int G = cnt * nk;
+  if ((blockIdx.x >> 3) & 1)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
   const int arow = tid >> 2, au = tid & 3;   // A: one (row, 8-float octet) per thread
   const int wrow = tid >> 3, wu = tid & 7;   // W image: unit wu of rows wrow + 64 i
@@ -599,32 +633,45 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
     }
   };
 
-  // row statistic of the workgroup: per-(i, r) partial sums of this wave -> LDS -> sum over the 4 N-waves.
-  // LDS addresses are one per-lane base (re-derived per call, so that nothing is hoisted out of the tile
-  // loop and spilled) + compile-time offsets.
-  auto block_row_sum = [&](float (&s)[2][16], float* scratch) {
-    float mine = 0.f;
+  // Row statistic of the workgroup.  Stage 1: every wave reduces its 96 columns of each of its 64 rows
+  // (DPP) and the upper-row lanes write the per-wave partials to part[row][N-wave]; stage 2: thread `row`
+  // adds the four partials in a fixed order (deterministic) into tot[row]; stage 3: each lane fetches the
+  // totals of its 32 rows as 8 float4 (rows r&3 are consecutive).  LDS addresses are one per-lane base
+  // (re-derived per call, so that nothing is hoisted out of the tile loop and spilled) + constants.
+  auto block_row_sum = [&](float (&s)[2][16], float* part) {
+    float* tot = part + BM * 4;
+    float m0 = 0.f, m1 = 0.f;
+    const int l15 = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[i][r] = half_wave_sum(s[i][r]);
-        mine = (l31 == i * 16 + r) ? s[i][r] : mine;
-      }
-    int rbase = (wm * 64 + 4 * half) * 4;  // float index of tile row (wm*64 + 4*half), N-wave 0
+    for (int r = 0; r < 16; ++r) {
+      s[0][r] = half_wave_sum_hi(s[0][r]);
+      s[1][r] = half_wave_sum_hi(s[1][r]);
+      m0 = (l15 == r) ? s[0][r] : m0;
+      m1 = (l15 == r) ? s[1][r] : m1;
+    }
+    int rbase = wm * 64 + 4 * half;  // first tile row of this lane's row set
     asm volatile("" : "+v"(rbase));
-    {
-      const int i = l31 >> 4, r = l31 & 15;
-      scratch[rbase + (i * 32 + (r & 3) + 8 * (r >> 2)) * 4 + wn] = mine;
+    if (lane & 16) {  // lanes holding complete half-wave sums; lane l15 publishes rows r = l15 of both i
+      const int rr = (l15 & 3) + 8 * (l15 >> 2);
+      part[(rbase + rr) * 4 + wn] = m0;
+      part[(rbase + 32 + rr) * 4 + wn] = m1;
     }
     __syncthreads();
-    const float* rd = scratch + rbase;
+    if (tid < BM) {
+      const float4 q = *reinterpret_cast<const float4*>(part + tid * 4);
+      tot[tid] = (q.x + q.y) + (q.z + q.w);
+    }
+    __syncthreads();
+    const float* rd = tot + rbase;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float4 q = *reinterpret_cast<const float4*>(rd + (i * 32 + (r & 3) + 8 * (r >> 2)) * 4);
-        s[i][r] = (q.x + q.y) + (q.z + q.w);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 q = *reinterpret_cast<const float4*>(rd + i * 32 + 8 * g4);
+        s[i][4 * g4 + 0] = q.x;
+        s[i][4 * g4 + 1] = q.y;
+        s[i][4 * g4 + 2] = q.z;
+        s[i][4 * g4 + 3] = q.w;
       }
   };
 
@@ -687,7 +734,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
         }
         s[i][r] = t;
       }
-    block_row_sum(s, red + BM * 4);
+    block_row_sum(s, red + BM * 5);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -736,7 +783,7 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
                           const float* gamma, const float* beta, float eps, float* C, int M, int N, int K,
                           hipStream_t s) {
   if (N != 384 || K % 64 != 0 || K < 128 || M % 128 != 0) return false;
-  constexpr int smem = 2 * (128 + 384) * 9 * 16 + 2 * 128 * 4 * 4;  // 151,552 B
+  constexpr int smem = 2 * (128 + 384) * 9 * 16 + 2 * 128 * 5 * 4;  // 152,576 B
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
@@ -749,7 +796,8 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
     attr_set = true;
   }
   const float a_scale = 16.0f;
-  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps};
+  static const int stagger = env_int("FDMI_LN_STAGGER", 0);
+  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps, stagger};
   const int ntiles = (M + 127) / 128;
   const int grid = ntiles < n_cu ? ntiles : n_cu;
   hipLaunchKernelGGL(gemm_f16x3_ln_kernel, dim3(grid), dim3(512), smem, s, p);

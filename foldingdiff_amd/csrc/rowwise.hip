@@ -8,6 +8,8 @@
 //   philox_fill      the perf-mode N(0,1) stream, exposed for tests
 // A token's d_model row is spread over the 64 lanes (column = lane + 64*j, coalesced
 // 256-byte wave accesses); reductions are xor-shuffle butterflies over the wavefront.
+#include <cstdlib>
+
 #include "fdmi_kernels.h"
 
 namespace fdmi {
@@ -18,6 +20,51 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+// sum over the 16 lanes of a DPP row (result in all 16): quad butterflies + the two mirror steps
+__device__ __forceinline__ float row16_sum(float v) {
+#define FD_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  FD_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+  FD_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+  FD_DPP_ADD(0x141);  // row_half_mirror
+  FD_DPP_ADD(0x140);  // row_mirror
+#undef FD_DPP_ADD
+  return v;
+}
+
+static int rowwise_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// ---- 16-lanes-per-token layout (d = 64 * NV, the released d = 384 -> NV = 6) ----
+// Lane k of a 16-lane group owns the float4 columns k + 16 j (j < NV): 256-byte coalesced group
+// accesses, row reductions are 4 DPP steps (no LDS round trips), 16 tokens per workgroup pass and a
+// grid-stride loop, so the per-column parameters (LayerNorm gamma / beta, bias, time embedding)
+// live in registers and the small weight matrix in LDS for the whole launch.
+template <int NV>
+__device__ __forceinline__ void row16_layernorm(float4 (&v)[NV], const float4 (&gm)[NV], const float4 (&bt)[NV], int d,
+                                                float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = row16_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+    q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+  }
+  const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j].x = v[j].x * rstd * gm[j].x + bt[j].x;
+    v[j].y = v[j].y * rstd * gm[j].y + bt[j].y;
+    v[j].z = v[j].z * rstd * gm[j].z + bt[j].z;
+    v[j].w = v[j].w * rstd * gm[j].w + bt[j].w;
+  }
 }
 
 // LayerNorm of a row held as v[j] = row[lane + 64 j]  (biased variance, rstd = 1/sqrt(var+eps))
@@ -77,10 +124,87 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
   }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void embed16_kernel(const float* __restrict__ x, const float* __restrict__ w_in,
+                                                      const float* __restrict__ b_in, const float* __restrict__ pos_emb,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, const float* __restrict__ time_table,
+                                                      const int* __restrict__ t_dev, float* __restrict__ h, int M, int L,
+                                                      int F) {
+  constexpr int d = 64 * NV;
+  extern __shared__ __attribute__((aligned(16))) float wT[];  // [F][d]: w_in transposed
+  for (int i = threadIdx.x; i < F * d; i += 256) {
+    const int f = i / d, c = i - f * d;
+    wT[i] = w_in[c * F + f];
+  }
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = *t_dev;
+  float4 bi[NV], gm[NV], bt[NV], tt[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = 4 * (k + 16 * j);
+    bi[j] = *reinterpret_cast<const float4*>(b_in + c);
+    gm[j] = *reinterpret_cast<const float4*>(gamma + c);
+    bt[j] = *reinterpret_cast<const float4*>(beta + c);
+    tt[j] = *reinterpret_cast<const float4*>(time_table + (size_t)t * d + c);
+  }
+  __syncthreads();
+  for (int tg = blockIdx.x; tg * 16 < M; tg += gridDim.x) {
+    const int tok = tg * 16 + g;
+    const int tc = tok < M ? tok : M - 1;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = bi[j];
+    for (int f = 0; f < F; ++f) {
+      const float xf = x[(size_t)tc * F + f];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(wT + f * d + 4 * (k + 16 * j));
+        v[j].x += xf * w.x; v[j].y += xf * w.y; v[j].z += xf * w.z; v[j].w += xf * w.w;
+      }
+    }
+    if (pos_emb) {  // absolute positions only (modelling.py:164-166)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float4 pe = *reinterpret_cast<const float4*>(pos_emb + (size_t)(tc % L) * d + 4 * (k + 16 * j));
+        v[j].x += pe.x; v[j].y += pe.y; v[j].z += pe.z; v[j].w += pe.w;
+      }
+    }
+    row16_layernorm<NV>(v, gm, bt, d, eps);
+    if (tok < M) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j)  // time embedding added AFTER the LayerNorm (modelling.py:472)
+        *reinterpret_cast<float4*>(h + (size_t)tok * d + 4 * (k + 16 * j)) =
+            make_float4(v[j].x + tt[j].x, v[j].y + tt[j].y, v[j].z + tt[j].z, v[j].w + tt[j].w);
+    }
+  }
+}
+
+template <int NV>
+static void launch_embed16(const float* x, const float* w_in, const float* b_in, const float* pos_emb, const float* gamma,
+                           const float* beta, float eps, const float* time_table, const int* t_dev, float* h, int M, int L,
+                           int F, hipStream_t s) {
+  int grid = (M + 15) / 16;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL((embed16_kernel<NV>), dim3(grid), dim3(256), (size_t)F * 64 * NV * 4, s, x, w_in, b_in, pos_emb, gamma,
+                     beta, eps, time_table, t_dev, h, M, L, F);
+}
+
+// FDMI_ROWWISE16=0 keeps the one-wave-per-token kernels (also the generic path for d % 64 != 0 or d > 512)
+static bool use_row16(int d) {
+  static const int on = rowwise_env_int("FDMI_ROWWISE16", 1);
+  return on && d % 64 == 0 && d >= 64 && d <= 512;
+}
+
 void launch_embed(const float* x, const float* w_in, const float* b_in, const float* pos_emb, const float* gamma,
                   const float* beta, float eps, const float* time_table, const int* t_dev, float* h, int B, int L, int F,
                   int d, hipStream_t s) {
   const int M = B * L;
+  if (use_row16(d)) {
+#define FD_E16(NV) case NV: launch_embed16<NV>(x, w_in, b_in, pos_emb, gamma, beta, eps, time_table, t_dev, h, M, L, F, s); return;
+    switch (d / 64) { FD_E16(1) FD_E16(2) FD_E16(3) FD_E16(4) FD_E16(5) FD_E16(6) FD_E16(7) FD_E16(8) }
+#undef FD_E16
+  }
   const dim3 grid((M + 3) / 4), block(256);
   const int nj = (d + 63) / 64;
 #define FD_EMBED(NJ)                                                                                             \
@@ -246,7 +370,86 @@ __global__ __launch_bounds__(256) void head_update_kernel(UpdateArgs a) {
   if (hist) hist[(size_t)(t_start - t) * a.M * F + o] = xn;
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void head_update16_kernel(UpdateArgs a) {
+  constexpr int d = 64 * NV;
+  extern __shared__ __attribute__((aligned(16))) float w2s[];  // [F][d]
+  const int F = a.F;
+  for (int i = threadIdx.x; i < F * d; i += 256) w2s[i] = a.w2[i];
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+  float4 gm[NV], bt[NV];
+  if (a.do_ln) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      gm[j] = *reinterpret_cast<const float4*>(a.gamma + 4 * (k + 16 * j));
+      bt[j] = *reinterpret_cast<const float4*>(a.beta + 4 * (k + 16 * j));
+    }
+  }
+  const float b2k = a.b2[k < F ? k : 0];
+  // per-call values (see UpdateDyn)
+  const int t = a.x_out ? *a.t_dev : 0;
+  const float* noise = a.noise;
+  float* hist = a.hist;
+  unsigned long long seed = a.seed;
+  long long seq_offset = a.seq_offset;
+  int t_start = a.t_start;
+  if (a.dyn) {
+    noise = a.dyn->noise; hist = a.dyn->hist; seed = a.dyn->seed; seq_offset = a.dyn->seq_offset; t_start = a.dyn->t_start;
+  }
+  float c1 = 0.f, btc = 0.f, c3 = 1.f, sg = 0.f;
+  if (a.x_out) { c1 = a.coef[t]; btc = a.coef[a.T + t]; c3 = a.coef[2 * a.T + t]; sg = a.coef[3 * a.T + t]; }
+  __syncthreads();
+  for (int tg = blockIdx.x; tg * 16 < a.M; tg += gridDim.x) {
+    const int tok = tg * 16 + g;
+    const int tc = tok < a.M ? tok : a.M - 1;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(a.g + (size_t)tc * d + 4 * (k + 16 * j));
+    if (a.do_ln) row16_layernorm<NV>(v, gm, bt, d, a.ln_eps);
+    // dense2: F dot products of length d; lane f of the group keeps result f
+    float mine = 0.f;
+    for (int f = 0; f < F; ++f) {
+      float partial = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(w2s + f * d + 4 * (k + 16 * j));
+        partial += (v[j].x * w.x + v[j].y * w.y) + (v[j].z * w.z + v[j].w * w.w);
+      }
+      partial = row16_sum(partial);
+      mine = (k == f) ? partial + b2k : mine;
+    }
+    if (k < F && tok < a.M) {
+      const size_t o = (size_t)tok * F + k;
+      if (a.eps_out) a.eps_out[o] = mine;
+      if (a.x_out) {
+        // model_mean = sqrt_recip_alphas_t * (x - betas_t * eps / sqrt_one_minus_alphas_cumprod_t)   (sampling.py:62-67)
+        float xn = __fmul_rn(c1, __fsub_rn(a.x[o], __fdiv_rn(__fmul_rn(btc, mine), c3)));
+        if (t > 0) {  // sampling.py:69-75
+          const float z = noise ? noise[(size_t)t * a.noise_stride + o]
+                                : philox_normal(seed, t, seq_offset + tok / a.L, tok % a.L, k);
+          xn = __fadd_rn(xn, __fmul_rn(sg, z));
+        }
+        if ((a.angle_mask >> k) & 1u) xn = wrap_pi(xn);
+        a.x_out[o] = xn;
+        if (hist) hist[(size_t)(t_start - t) * a.M * F + o] = xn;
+      }
+    }
+  }
+}
+
+template <int NV>
+static void launch_head_update16(const UpdateArgs& a, hipStream_t s) {
+  int grid = (a.M + 15) / 16;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL((head_update16_kernel<NV>), dim3(grid), dim3(256), (size_t)a.F * 64 * NV * 4, s, a);
+}
+
 void launch_head_update(const UpdateArgs& a, hipStream_t s) {
+  if (use_row16(a.d) && a.F <= 16) {
+#define FD_H16(NV) case NV: launch_head_update16<NV>(a, s); return;
+    switch (a.d / 64) { FD_H16(1) FD_H16(2) FD_H16(3) FD_H16(4) FD_H16(5) FD_H16(6) FD_H16(7) FD_H16(8) }
+#undef FD_H16
+  }
   const dim3 grid((a.M + 3) / 4), block(256);
   const int nj = (a.d + 63) / 64;
 #define FD_HU(NJ) hipLaunchKernelGGL((head_update_kernel<NJ>), grid, block, 0, s, a)

@@ -108,7 +108,9 @@ void fd_destroy(fd_model* m);
 
 /* Runtime switches:
  *   "fuse_ln"    1: residual + LayerNorm run in the epilogue of the attention-output and
- *                FFN-down GEMMs; 0 (default): separate LayerNorm kernel (same arithmetic).
+ *                FFN-down GEMMs (shapes without a fused instantiation fall back); 0: separate
+ *                LayerNorm kernel (same arithmetic); -1 (default): 1 with FD_PREC_F16X3, 0 with
+ *                FD_PREC_F32 (what is fastest on MI355X).
  *   "use_graph"  1 (default): the per-step kernel sequence is replayed from a hipGraph;
  *                0: eager launches.
  *   "attn_f16"   with FD_PREC_F16X3 only -- 1 (default): attention contractions on the fp16x3

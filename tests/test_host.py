@@ -158,3 +158,40 @@ def test_step_noise_draw_order_matches_reference():
     _ = torch.randn(4, 128, 6)  # the initial sample_noise draw
     z = sampling._draw_step_noise(int(g["T"]), (4, 48, 6))
     assert np.array_equal(z, g["step_noise"])
+
+
+def test_gelu_rational_erf_accuracy():
+    """The fp16x3 GEMM epilogue evaluates erf as a rational function (csrc/gemm_f16x3.hip:erf_rational,
+    coefficients restated here): it must stay in libm-erff's error class against float64 erf, and the
+    GELU built on it within torch's own fp32 GELU error (the exact-erf "gelu" of modelling.py:195-196)."""
+    import math
+    import re
+    f = np.float32
+    src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "gemm_f16x3.hip")).read()
+    body = src[src.index("float erf_rational(float x)"):src.index("// exact-erf GELU")]
+    consts = [f(c) for c in re.findall(r"(-?\d\.\d+e-\d+)f", body)]
+    assert len(consts) == 12, consts            # 7 numerator + 5 denominator coefficients, in evaluation order
+    alpha, beta = consts[:7], consts[7:]
+
+    def erf32(x):
+        x = np.clip(x.astype(f), f(-4), f(4))
+        x2 = x * x
+        p = np.full_like(x, alpha[0])
+        for a in alpha[1:]:
+            p = p * x2 + a
+        q = np.full_like(x, beta[0])
+        for b in beta[1:]:
+            q = q * x2 + b
+        return ((p * x) / q).astype(f)
+
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([np.linspace(-6, 6, 600001), rng.standard_normal(300000) * 1.5,
+                         np.logspace(-8, 0, 50000)]).astype(f)
+    erf64 = np.vectorize(math.erf)
+    err = np.abs(erf32(xs).astype(np.float64) - erf64(xs.astype(np.float64))).max()
+    assert err <= 5e-7, err
+    gelu64 = 0.5 * xs.astype(np.float64) * (1 + erf64(xs.astype(np.float64) / math.sqrt(2)))
+    h = f(0.5) * xs
+    got = (h * erf32(xs * f(0.70710678118654752440)) + h).astype(np.float64)
+    torch_err = np.abs(torch.nn.functional.gelu(torch.from_numpy(xs)).double().numpy() - gelu64).max()
+    assert np.abs(got - gelu64).max() <= max(2e-6, 1.5 * torch_err)
