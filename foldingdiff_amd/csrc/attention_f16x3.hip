@@ -27,6 +27,8 @@
 //   * O^T = V^T . P^T : A = Vt (LDS), B = P (registers, split to fp16 hi/lo after the softmax).  In the
 //     transposed form queries stay in lanes, so the online-softmax rescale is a per-lane scalar.
 // Scores, probabilities and the context accumulate in fp32; nothing but q|k|v and ctx touches HBM.
+#include <cstdlib>
+
 #include "fdmi_kernels.h"
 
 namespace fdmi {
@@ -71,8 +73,11 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
   }
 }
 
-template <int T, bool REL>
-__global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* __restrict__ qkv,
+// OCC = workgroups per CU the register allocation is capped for (2: up to 256 VGPRs, no spills;
+// 3: 168 VGPRs, T = 4 spills ~100 dwords -- experiment knob FDMI_ATTN_OCC, 53.5 KB of LDS per workgroup
+// allows three).
+template <int T, bool REL, int OCC>
+__global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float* __restrict__ qkv,
                                                                const u32x4* __restrict__ demb, float r_scale,
                                                                const int* __restrict__ lens, float* __restrict__ ctx,
                                                                int L, int H, int maxpos) {
@@ -344,22 +349,30 @@ __global__ __launch_bounds__(256 * HPB, 2) void attn_f16x3_kernel(const float* _
   }
 }
 
-template <int T, bool REL>
-static void launch_t(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
+template <int T, bool REL, int OCC>
+static void launch_occ(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
                      int maxpos, hipStream_t s) {
   constexpr int LP = 32 * T;
   const size_t smem = (size_t)HPB * LP * KROW + (size_t)HPB * 32 * (4 * LP + 8) +
                       (REL ? sizeof(float) * 4 * HPB * 32 * RLD : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL, OCC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int hgroups = (H + HPB - 1) / HPB;
   const int nqg = (L + LP - 1) / LP;
-  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
+  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL, OCC>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
                      static_cast<const u32x4*>(demb), r_scale, lens, ctx, L, H, maxpos);
+}
+
+template <int T, bool REL>
+static void launch_t(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
+                     int maxpos, hipStream_t s) {
+  static const int occ = [] { const char* e = getenv("FDMI_ATTN_OCC"); return e ? atoi(e) : 2; }();
+  if (occ == 3) launch_occ<T, REL, 3>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
+  else launch_occ<T, REL, 2>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
 }
 
 }  // namespace a16

@@ -525,7 +525,6 @@ struct GemmLnArgs {
   float* C;
   int M, K;
   float a_scale, out_scale, eps;
-  int stagger;  // experiment: every other workgroup of an XCD starts `stagger` x ~3.4 us late (de-phases the HBM-heavy epilogues)
 };
 
 // Sum over the 32 lanes of this lane's half-wave, DPP only (no LDS round trip).  The result is
@@ -543,6 +542,9 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
   return v;
 }
 
+// DBG (ablation builds via FDMI_LN_DBG, results wrong by design): 1 = no residual loads, 2 = no output
+// stores, 3 = no LayerNorm reductions.
+template <int DBG>
 __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   constexpr int BM = 128, BN = 384, BK = 32, RQ = 9, NTHR = 512, NT = 3;
   constexpr int WU = BN * 8 / NTHR;  // 6 W image units (16 B) per thread per k-tile
@@ -560,8 +562,6 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   const int cnt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
   if (cnt == 0) return;
   const int G = cnt * nk;
-  if ((blockIdx.x >> 3) & 1)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
   const int arow = tid >> 2, au = tid & 3;   // A: one (row, 8-float octet) per thread
   const int wrow = tid >> 3, wu = tid & 7;   // W image: unit wu of rows wrow + 64 i
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   // across the epilogue; the second set is re-issued after it (see the stream loop below).
   // Addresses are (wave-uniform row base in SGPRs) + (one per-lane offset): a per-row VGPR address
   // pair would cost 64 registers and spill.
-  auto epilogue = [&](int ti) {   // M % 128 == 0 (host guarantees): every tile is full
+  auto epilogue = [&](int ti, int g_next) {   // M % 128 == 0 (host guarantees): every tile is full
     const int row0 = __builtin_amdgcn_readfirstlane((first + ti * stride) * BM + wm * 64);
     int loff = 4 * half * BN + wn * 96 + l31;   // lane part of every element offset
     asm volatile("" : "+v"(loff));               // re-derived per tile: nothing address-like is hoisted out of the tile loop
@@ -696,14 +696,15 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj) bz[jj] = p.bias[wn * 96 + jj * 32 + l31];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[0][r] = (rbase + ((r & 3) + 8 * (r >> 2)) * BN)[loff];
+    for (int r = 0; r < 16; ++r) rv[0][r] = DBG == 1 ? 0.f : (rbase + ((r & 3) + 8 * (r >> 2)) * BN)[loff];
 #pragma unroll
     for (int b = 0; b < 2 * NT; ++b) {
       const int jj = b >> 1, i = b & 1;
       if (b + 1 < 2 * NT) {
         const int jn = (b + 1) >> 1, in = (b + 1) & 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[(b + 1) & 1][r] = (rbase + (in * 32 + (r & 3) + 8 * (r >> 2)) * BN)[loff + jn * 32];
+        for (int r = 0; r < 16; ++r)
+          rv[(b + 1) & 1][r] = DBG == 1 ? 0.f : (rbase + (in * 32 + (r & 3) + 8 * (r >> 2)) * BN)[loff + jn * 32];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
       gm[jj] = p.gamma[wn * 96 + jj * 32 + l31];
       bt[jj] = p.beta[wn * 96 + jj * 32 + l31];
     }
-    block_row_sum(s, red);
+    if constexpr (DBG != 3) block_row_sum(s, red);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -734,18 +735,25 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
         }
         s[i][r] = t;
       }
-    block_row_sum(s, red + BM * 5);
+    if constexpr (DBG != 3) block_row_sum(s, red + BM * 5);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[i][r] = 1.0f / sqrtf(s[i][r] * (1.0f / BN) + p.eps);
+    // The second prefetch set of the next tile goes out BEFORE the 96 stores: vmcnt retires in order, so a
+    // load issued behind them could only be consumed after every store of this tile has drained.
+    gload(ra1, rw1, g_next);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool do_store = DBG != 2 || p.M < 0;
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          (cbase + (i * 32 + (r & 3) + 8 * (r >> 2)) * BN)[loff + jj * 32] = acc[i][jj][r] * s[i][r] * gm[jj] + bt[jj];
+        for (int r = 0; r < 16; ++r) {
+          const float o = acc[i][jj][r] * s[i][r] * gm[jj] + bt[jj];
+          if (do_store) (cbase + (i * 32 + (r & 3) + 8 * (r >> 2)) * BN)[loff + jj * 32] = o;
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -772,9 +780,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
     const int g0 = ti * nk;
     pair(g0, StreamNo{});
     for (int pi = 1; pi < npairs - 1; ++pi) pair(g0 + 2 * pi, StreamNo{});
-    pair(g0 + nk - 2, StreamYes{});   // the load of stream position g0+nk+2 is issued after the epilogue
-    epilogue(ti);
-    gload(ra1, rw1, g0 + nk + 2);
+    pair(g0 + nk - 2, StreamYes{});   // the load of stream position g0+nk+2 is issued inside the epilogue
+    epilogue(ti, g0 + nk + 2);
     zero_acc();
   }
 }
@@ -786,9 +793,11 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
   constexpr int smem = 2 * (128 + 384) * 9 * 16 + 2 * 128 * 5 * 4;  // 152,576 B
   static bool attr_set = false;
   static int n_cu = 256;
+  static const int dbg = env_int("FDMI_LN_DBG", 0);  // ablation only
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    for (const void* f : {reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel<0>), reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel<1>),
+                          reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel<2>), reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel<3>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -796,11 +805,15 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
     attr_set = true;
   }
   const float a_scale = 16.0f;
-  static const int stagger = env_int("FDMI_LN_STAGGER", 0);
-  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps, stagger};
+  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps};
   const int ntiles = (M + 127) / 128;
   const int grid = ntiles < n_cu ? ntiles : n_cu;
-  hipLaunchKernelGGL(gemm_f16x3_ln_kernel, dim3(grid), dim3(512), smem, s, p);
+  switch (dbg) {
+    case 1: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<1>, dim3(grid), dim3(512), smem, s, p); break;
+    case 2: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<2>, dim3(grid), dim3(512), smem, s, p); break;
+    case 3: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<3>, dim3(grid), dim3(512), smem, s, p); break;
+    default: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<0>, dim3(grid), dim3(512), smem, s, p); break;
+  }
   return true;
 }
 
