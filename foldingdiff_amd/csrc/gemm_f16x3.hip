@@ -46,6 +46,9 @@ struct GemmSplitArgs {
   float out_scale;  // 1 / (a_scale * w_scale)
 };
 
+struct StreamNo { static constexpr bool value = false; };
+struct StreamYes { static constexpr bool value = true; };
+
 __device__ __forceinline__ int xcd_remap16(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_persist_kernel(GemmSplitA
   const int wrow = tid / (8 / WU), wpart = WU * (tid % (8 / WU));  // W image: WU x 16 B per thread
 
   f32x16 acc[2][2];
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_persist_kernel(GemmSplitA
   float4 ra0[4], ra1[4];
   u32x4 rw0[WU], rw1[WU];
   // unconditional loads, indices clamped (see the non-persistent kernel)
-  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[WU], int g) {
+  auto gload = [&](float4 (&ra)[4], u32x4 (&rw)[WU], int g) __attribute__((always_inline)) {
     g = g < G ? g : G - 1;
     const int ti = g / nk, kt = g - ti * nk;
     const int tile = first + ti * stride;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_persist_kernel(GemmSplitA
 #pragma unroll
     for (int i = 0; i < WU; ++i) rw[i] = w[i];
   };
-  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[WU], int buf) {
+  auto lstore = [&](const float4 (&ra)[4], const u32x4 (&rw)[WU], int buf) __attribute__((always_inline)) {
     u32x4* S = smem + buf * STAGE;
     u32x4 h0, l0, h1, l1;
     split8(ra[0], ra[1], p.a_scale, h0, l0);
@@ -377,9 +380,9 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_persist_kernel(GemmSplitA
 #pragma unroll
     for (int i = 0; i < WU; ++i) wr[i] = rw[i];
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const u32x4* S = smem + buf * STAGE;
-    if constexpr (VAR == 0) {
+    if constexpr (VAR == 0 || VAR == 3) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         f16x8 ah[2], al[2], bh[2], bl[2];
@@ -444,13 +447,83 @@ __global__ __launch_bounds__(128 * WM) void gemm_f16x3_persist_kernel(GemmSplitA
       if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
     }
   };
-  auto epilogue = [&](int ti) {
+  auto epilogue = [&](int ti) __attribute__((always_inline)) {
     const int tile = first + ti * stride;
     store_tile<EPI>(p, acc, (tile / tiles_n) * BM + wm * 64, (tile % tiles_n) * BN + wn * 64, half, l31);
   };
 
+  if constexpr (VAR == 3) {
+    // Ping-pong schedule (8 waves): waves 0-3 ("A") and 4-7 ("B") share the four SIMDs pairwise and run
+    // one barrier phase apart, so on every SIMD one wave is in its MFMA phase while the other splits and
+    // stages operands (in the lock-step schedule both waves of a SIMD are in the same phase and the MFMA
+    // pipe idles during every staging phase).  Phase table (stream position p; buffer p & 1):
+    //     A: store(p) at phase 2p,     compute(p) at phase 2p + 3
+    //     B: store(p) at phase 2p + 1, compute(p) at phase 2p + 2
+    // every phase ends in a workgroup barrier; position p is complete after phase 2p + 1, read in phases
+    // 2p + 2 / 2p + 3, and its buffer is rewritten (position p + 2) from phase 2p + 4 on.
+    static_assert(VAR != 3 || WM == 4, "ping-pong needs the 8-wave workgroup");
+    const int role = __builtin_amdgcn_readfirstlane(wid >> 2);
+    const int npairs = nk / 2;  // >= 2 (host guarantees)
+    gload(ra1, rw1, 0);
+    gload(ra0, rw0, 1);
+    if (role == 0) {
+      lstore(ra1, rw1, 0);
+      gload(ra1, rw1, 2);
+      __syncthreads();  // phase 0
+      __syncthreads();  // phase 1 (B stores position 0)
+      auto step = [&](int g, int ti, auto last) __attribute__((always_inline)) {
+        lstore(ra0, rw0, 1);  // position g + 1
+        gload(ra0, rw0, g + 3);
+        __syncthreads();
+        compute(0);           // position g
+        __syncthreads();
+        lstore(ra1, rw1, 0);  // position g + 2 (the last pair of a tile: already the next tile)
+        gload(ra1, rw1, g + 4);
+        __syncthreads();
+        compute(1);           // position g + 1
+        if constexpr (decltype(last)::value) {
+          epilogue(ti);
+          zero_acc();
+        }
+        __syncthreads();
+      };
+      for (int ti = 0; ti < cnt; ++ti) {
+        const int g0 = ti * nk;
+        step(g0, ti, StreamNo{});
+        for (int pi = 1; pi < npairs - 1; ++pi) step(g0 + 2 * pi, ti, StreamNo{});
+        step(g0 + nk - 2, ti, StreamYes{});
+      }
+    } else {
+      __syncthreads();  // phase 0 (A stores position 0)
+      auto step = [&](int g, int ti, auto last) __attribute__((always_inline)) {
+        lstore(ra1, rw1, 0);  // position g
+        gload(ra1, rw1, g + 2);
+        __syncthreads();
+        compute(0);           // position g
+        __syncthreads();
+        lstore(ra0, rw0, 1);  // position g + 1
+        gload(ra0, rw0, g + 3);
+        __syncthreads();
+        compute(1);           // position g + 1
+        if constexpr (decltype(last)::value) {
+          epilogue(ti);
+          zero_acc();
+        }
+        __syncthreads();
+      };
+      for (int ti = 0; ti < cnt; ++ti) {
+        const int g0 = ti * nk;
+        step(g0, ti, StreamNo{});
+        for (int pi = 1; pi < npairs - 1; ++pi) step(g0 + 2 * pi, ti, StreamNo{});
+        step(g0 + nk - 2, ti, StreamYes{});
+      }
+      __syncthreads();  // pairs with A's last barrier
+    }
+    return;
+  }
+
   // stream positions: even g -> LDS buffer 0 / register set 1, odd g -> buffer 1 / set 0
-  auto pair = [&](int g) {
+  auto pair = [&](int g) __attribute__((always_inline)) {
     compute(0);
     lstore(ra0, rw0, 1);
     gload(ra0, rw0, g + 3);
@@ -511,9 +584,6 @@ static void launch_persist(const GemmSplitArgs& p, hipStream_t s) {
 // rowwise.hip:row_layernorm): the pre-LN tensor never goes to HBM and the standalone LayerNorm
 // launch (201 MB of traffic per call at M = 65536) disappears.
 static int env_int(const char* name, int dflt);
-
-struct StreamNo { static constexpr bool value = false; };
-struct StreamYes { static constexpr bool value = true; };
 
 struct GemmLnArgs {
   const float* A;
@@ -872,6 +942,15 @@ void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_sca
     case EPI_BIAS_GELU: launch_persist<EPI_BIAS_GELU, 0, W>(p, s); break; \
     default: launch_persist<EPI_BIAS_RESID, 0, W>(p, s); break;           \
   }
+    static const int var = env_int("FDMI_GEMM_VAR", 0);  // 3: ping-pong wave schedule (256-row workgroups)
+    if (var == 3 && pbm != 128) {
+      switch (epilogue) {
+        case EPI_BIAS: launch_persist<EPI_BIAS, 3, 4>(p, s); break;
+        case EPI_BIAS_GELU: launch_persist<EPI_BIAS_GELU, 3, 4>(p, s); break;
+        default: launch_persist<EPI_BIAS_RESID, 3, 4>(p, s); break;
+      }
+      return;
+    }
     if (pbm == 128) { FD_PERSIST(2) } else { FD_PERSIST(4) }
 #undef FD_PERSIST
     return;
