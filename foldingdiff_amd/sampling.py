@@ -217,6 +217,68 @@ def sample(
     return results
 
 
+@torch.no_grad()
+def reverse_from(model, x_t: torch.Tensor, lengths: Sequence[int], t_start: int, betas: torch.Tensor,
+                 is_angle: Union[bool, List[bool]] = True) -> torch.Tensor:
+    """Reverse steps t = t_start, t_start-1, ..., 0 from a partially noised ``x_t`` [B, L, F]; returns the
+    final [B, L, F] on the CPU.  This is the loop of the reference's ``get_reconstruction_error``
+    (foldingdiff/sampling.py:320-331): ``p_sample`` then ``modulo_with_wrapped_range(img)`` with its
+    default bounds, i.e. EVERY feature is wrapped to [-pi, pi) (``is_angle=True``).  Per-step noise: the
+    reference's draw order from the global CPU generator (``NOISE_MODE="torch"``) or Philox."""
+    T = len(betas)
+    assert 0 <= t_start < T, f"t_start={t_start} outside the {T}-step schedule"
+    h = model.prepare(betas, is_angle)
+    x0 = _as_f32(x_t)
+    B, L, F = x0.shape
+    lens = _lens_array(lengths, B, L)
+    if NOISE_MODE == "torch":
+        zs = _draw_step_noise(t_start + 1, (B, L, F))
+        zptr, seed = zs.ctypes.data_as(C.c_void_p), 0
+    elif NOISE_MODE == "philox":
+        zs, zptr = None, None
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    else:
+        raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
+    out = np.empty((1, B, L, F), dtype=np.float32)
+    _binding.check(_binding.load().fd_sample(h, x0.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, L,
+                                             t_start, zptr, C.c_uint64(seed), out.ctypes.data_as(C.c_void_p), 0))
+    return torch.from_numpy(out[0])
+
+
+@torch.no_grad()
+def reconstruct(model, dset, noise_timesteps: int = 250, bs: int = 512):
+    """Device part of ``get_reconstruction_error`` (foldingdiff/sampling.py:287-341): forward-noise every
+    item of ``dset`` (a ``NoisedAnglesDataset`` over real data) to ``t = noise_timesteps`` and denoise it
+    again.  Returns (reconstructed, truth, filenames): per item an array [len_i, F] each."""
+    recon, truth, files = [], [], []
+    for start in range(0, len(dset), bs):
+        idx_batch = list(range(start, min(start + bs, len(dset))))
+        items = [dset.__getitem__(idx, use_t_val=noise_timesteps) for idx in idx_batch]
+        img = torch.stack([it["corrupted"] for it in items]).clone()
+        assert img.ndim == 3
+        lengths = [int(torch.as_tensor(it["lengths"]).reshape(-1)[0]) for it in items]
+        files.extend(dset.filenames[i] for i in idx_batch)
+        # the reference iterates t = noise_timesteps-1 ... 0 whatever t the items were noised at
+        final = reverse_from(model, img, lengths, noise_timesteps - 1, dset.alpha_beta_terms["betas"], is_angle=True)
+        for i, l in enumerate(lengths):
+            recon.append(final[i, :l].numpy())
+            truth.append(items[i]["angles"][:l].cpu().numpy())
+    return recon, truth, files
+
+
+def get_reconstruction_error(model, dset, noise_timesteps: int = 250, bs: int = 512, scorer=None):
+    """Reference signature + ``scorer``: TM-align (an external binary) and the PDB writer are outside this
+    path, so the caller supplies ``scorer(reconst_angles, truth_angles, truth_pdb_file) -> (score,
+    score_coord)`` -- the role of the reference's ``_score_angles`` (foldingdiff/sampling.py:266-284).
+    Returns (scores, coord_scores) as the reference does."""
+    if scorer is None:
+        raise NotImplementedError("pass scorer=...: TM-score evaluation is not part of the MI355X hot path; "
+                                  "use reconstruct() for the angle sets")
+    recon, truth, files = reconstruct(model, dset, noise_timesteps=noise_timesteps, bs=bs)
+    scores, coord_scores = zip(*(scorer(r, t, f) for r, t, f in zip(recon, truth, files)))
+    return np.array(scores), np.array(coord_scores)
+
+
 def sample_simple(model_dir: str, n: int = 10, sweep_lengths: Tuple[int, int] = (50, 128)):
     """Load model + dummy dataset from ``model_dir`` and return one DataFrame of final
     angles per sampled backbone."""

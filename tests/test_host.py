@@ -195,3 +195,48 @@ def test_gelu_rational_erf_accuracy():
     got = (h * erf32(xs * f(0.70710678118654752440)) + h).astype(np.float64)
     torch_err = np.abs(torch.nn.functional.gelu(torch.from_numpy(xs)).double().numpy() - gelu64).max()
     assert np.abs(got - gelu64).max() <= max(2e-6, 1.5 * torch_err)
+
+
+class _ToyAngles:
+    """The synthetic dataset of tests/golden/make_golden_noising.py, rebuilt from the fixture."""
+    feature_names = {"angles": ["phi", "psi", "omega", "tau", "CA:C:1N", "C:1N:1CA"]}
+    feature_is_angular = {"angles": [True] * 6}
+
+    def __init__(self, g):
+        self.angles, self.lengths, self.pad = torch.from_numpy(g["angles"]), g["lengths"].tolist(), int(g["pad"])
+        self.filenames = [f"toy_{i}.pdb" for i in range(len(self.lengths))]
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def __getitem__(self, index, ignore_zero_center=False):
+        l = self.lengths[index]
+        mask = torch.zeros(self.pad)
+        mask[:l] = 1.0
+        return {"angles": self.angles[index].clone(), "attn_mask": mask, "position_ids": torch.arange(self.pad),
+                "lengths": torch.tensor(l, dtype=torch.int64)}
+
+
+def test_forward_noising_matches_reference_bitwise():
+    """NoisedAnglesDataset.__getitem__ (q(x_t | x_0)) against the reference's own class under the
+    same torch seed: corrupted values, the noise and t are bit-identical (tests/golden/ref_reconstruct.npz)."""
+    g = golden("ref_reconstruct.npz")
+    ds = datasets.NoisedAnglesDataset(_ToyAngles(g), dset_key="angles", timesteps=int(g["T"]), beta_schedule="cosine")
+    assert len(ds) == 5 and ds.filenames[3] == "toy_3.pdb"
+    torch.manual_seed(int(g["seed"]))
+    for i in range(5):
+        it = ds.__getitem__(i, use_t_val=int(g["noise_timesteps"]))
+        assert np.array_equal(it["corrupted"].numpy(), g[f"corrupted{i}"])
+        assert np.array_equal(it["known_noise"].numpy(), g[f"known_noise{i}"])
+        assert np.array_equal(it["t"].numpy(), g[f"t{i}"])
+        assert set(it) >= {"angles", "attn_mask", "position_ids", "lengths", "sqrt_alphas_cumprod_t",
+                           "sqrt_one_minus_alphas_cumprod_t"}
+    # the reference's denoising loop draws its step noise here; skip the same number of values
+    nt, B = int(g["noise_timesteps"]), 5
+    for _ in range(nt - 1):
+        torch.randn(B, int(g["pad"]), 6)
+    it = ds[2]
+    assert np.array_equal(it["t"].numpy(), g["rand_t"])
+    assert np.array_equal(it["corrupted"].numpy(), g["rand_corrupted"])
+    with pytest.raises(NotImplementedError):
+        sampling.get_reconstruction_error(None, ds)
