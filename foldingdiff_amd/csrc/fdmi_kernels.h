@@ -36,6 +36,10 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
                           const float* gamma, const float* beta, float eps, float* C, int M, int N, int K,
                           hipStream_t s);
 
+// Plain-epilogue GEMM on the 128 x 384 tiling of the LN-fused kernel (experiment; false if the shape does not fit).
+bool launch_gemm_f16x3_wide(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias, float* C,
+                            int M, int N, int K, hipStream_t s);
+
 // y[r,:] = LN(x[r,:]) * gamma + beta, rows of length d (d <= 1024), one wave per row.
 void launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int d,
                       hipStream_t s);

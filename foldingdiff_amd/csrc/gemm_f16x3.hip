@@ -595,6 +595,7 @@ struct GemmLnArgs {
   float* C;
   int M, K;
   float a_scale, out_scale, eps;
+  int N;  // row length of C (= 384 for the LayerNorm epilogue; a multiple of 384 for the plain epilogues)
 };
 
 // Sum over the 32 lanes of this lane's half-wave, DPP only (no LDS round trip).  The result is
@@ -614,7 +615,10 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
 
 // DBG (ablation builds via FDMI_LN_DBG, results wrong by design): 1 = no residual loads, 2 = no output
 // stores, 3 = no LayerNorm reductions.
-template <int DBG>
+// PLAIN >= 0: the same 128 x 384 tiling with a plain bias (EPI_BIAS) / bias + GELU (EPI_BIAS_GELU) epilogue for
+// N a multiple of 384 (QKV, FFN-up, head dense1: "wide tile" experiment FDMI_GEMM_WIDE) -- each A panel is
+// split 3x less often than with 128-column tiles.
+template <int DBG, int PLAIN = -1>
 __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   constexpr int BM = 128, BN = 384, BK = 32, RQ = 9, NTHR = 512, NT = 3;
   constexpr int WU = BN * 8 / NTHR;  // 6 W image units (16 B) per thread per k-tile
@@ -626,10 +630,15 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
   const int half = lane >> 5, l31 = lane & 31;
-  const int ntiles = (p.M + BM - 1) / BM;
+  const int tiles_n = PLAIN >= 0 ? p.N / BN : 1;
+  const int ntiles = (p.M / BM) * tiles_n;
   const int K = p.K, nk = K / BK;
-  const int first = blockIdx.x, stride = gridDim.x;
-  const int cnt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  // tiles are dealt XCD-aware, n fastest (see the persistent kernel above): the workgroups of an XCD take
+  // neighbouring tiles at the same time, so the column tiles of one A panel share that XCD's L2
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int tlo = (int)((long long)ntiles * xcd / 8), thi = (int)((long long)ntiles * (xcd + 1) / 8);
+  const int first = tlo + jx, stride = per;
+  const int cnt = first < thi ? (thi - first + stride - 1) / stride : 0;
   if (cnt == 0) return;
   const int G = cnt * nk;
 
@@ -652,12 +661,13 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   auto gload = [&](float4 (&ra)[2], u32x4 (&rw)[WU], int g) {
     g = g < G ? g : G - 1;
     const int ti = g / nk, kt = g - ti * nk;
-    const int m0 = (first + ti * stride) * BM;
+    const int tile = first + ti * stride;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int r1 = m0 + arow < p.M ? m0 + arow : p.M - 1;
     const float* a1 = p.A + (size_t)r1 * K + kt * BK + 8 * au;
     ra[0] = *reinterpret_cast<const float4*>(a1);
     ra[1] = *reinterpret_cast<const float4*>(a1 + 4);
-    const u32x4* w = p.Wp + ((size_t)wrow * nk + kt) * 8 + wu;
+    const u32x4* w = p.Wp + ((size_t)(n0 + wrow) * nk + kt) * 8 + wu;
 #pragma unroll
     for (int i = 0; i < WU; ++i) rw[i] = w[(size_t)i * 64 * nk * 8];
   };
@@ -750,6 +760,32 @@ __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   // Addresses are (wave-uniform row base in SGPRs) + (one per-lane offset): a per-row VGPR address
   // pair would cost 64 registers and spill.
   auto epilogue = [&](int ti, int g_next) {   // M % 128 == 0 (host guarantees): every tile is full
+    if constexpr (PLAIN >= 0) {
+      const int tile = first + ti * stride;
+      const int prow0 = __builtin_amdgcn_readfirstlane((tile / tiles_n) * BM + wm * 64);
+      const int n0 = (tile % tiles_n) * BN;
+      int poff = 4 * half * p.N + n0 + wn * 96 + l31;
+      asm volatile("" : "+v"(poff));
+      float* pc = p.C + (size_t)prow0 * p.N;
+      float pb[NT];
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj) pb[jj] = p.bias[n0 + wn * 96 + jj * 32 + l31];
+      gload(ra1, rw1, g_next);  // ahead of the stores (see the LayerNorm epilogue)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float o = acc[i][jj][r] * p.out_scale + pb[jj];
+            if constexpr (PLAIN == EPI_BIAS_GELU) o = gelu_erf16(o);
+            (pc + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.N)[poff + jj * 32] = o;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      return;
+    }
     const int row0 = __builtin_amdgcn_readfirstlane((first + ti * stride) * BM + wm * 64);
     int loff = 4 * half * BN + wn * 96 + l31;   // lane part of every element offset
     asm volatile("" : "+v"(loff));               // re-derived per tile: nothing address-like is hoisted out of the tile loop
@@ -875,15 +911,46 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
     attr_set = true;
   }
   const float a_scale = 16.0f;
-  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps};
+  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, gamma, beta, C, M, K, a_scale, 1.0f / (a_scale * w_scale), eps, N};
   const int ntiles = (M + 127) / 128;
-  const int grid = ntiles < n_cu ? ntiles : n_cu;
+  int grid = n_cu / 8 * 8;
+  if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
   switch (dbg) {
     case 1: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<1>, dim3(grid), dim3(512), smem, s, p); break;
     case 2: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<2>, dim3(grid), dim3(512), smem, s, p); break;
     case 3: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<3>, dim3(grid), dim3(512), smem, s, p); break;
     default: hipLaunchKernelGGL(gemm_f16x3_ln_kernel<0>, dim3(grid), dim3(512), smem, s, p); break;
   }
+  return true;
+}
+
+// "Wide tile" variant of the plain GEMMs (experiment knob FDMI_GEMM_WIDE=1, see gemm_f16x3_ln_kernel): false
+// when the shape does not fit (N % 384, M % 128, K % 64).
+bool launch_gemm_f16x3_wide(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias, float* C,
+                            int M, int N, int K, hipStream_t s) {
+  if ((epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU) || N % 384 != 0 || K % 64 != 0 || K < 128 || M % 128 != 0)
+    return false;
+  constexpr int smem = 2 * (128 + 384) * 9 * 16 + 2 * 128 * 5 * 4;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel<0, EPI_BIAS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_ln_kernel<0, EPI_BIAS_GELU>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const float a_scale = 16.0f;
+  GemmLnArgs p{A, static_cast<const u32x4*>(Wp), bias, nullptr, nullptr, nullptr, C, M, K, a_scale, 1.0f / (a_scale * w_scale), 0.f, N};
+  const int ntiles = (M / 128) * (N / 384);
+  int grid = n_cu / 8 * 8;
+  if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+  if (epilogue == EPI_BIAS) hipLaunchKernelGGL((gemm_f16x3_ln_kernel<0, EPI_BIAS>), dim3(grid), dim3(512), smem, s, p);
+  else hipLaunchKernelGGL((gemm_f16x3_ln_kernel<0, EPI_BIAS_GELU>), dim3(grid), dim3(512), smem, s, p);
   return true;
 }
 
