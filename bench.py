@@ -45,7 +45,7 @@ PRECISION_INFO = {
     "f32": dict(peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
                 kernel="gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384; v_mfma_f32_32x32x2_f32)"),
     "f16x3": dict(peak=PEAK_F16_MFMA_TFLOPS, dtype="f32 (fp16 hi/lo split operands, 3x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
-                  kernel="gemm_f16x3_persist_kernel<EPI_BIAS,0,4> (QKV projection, M=B*L, N=1152, K=384; algorithmic FLOPs counted once, "
+                  kernel="gemm_f16x3_ln_kernel<0,EPI_BIAS> = 128x384-tile split GEMM (QKV projection, M=B*L, N=1152, K=384; algorithmic FLOPs counted once, "
                          "the 3 MFMAs per product are overhead against the dense fp16 peak)"),
 }
 

@@ -338,9 +338,9 @@ int harvest(fd_model* m) {
 // p_sample update and wrap (sampling.py:62-75, :119-130), as a fixed kernel sequence.
 void gemm(fd_model* m, int epi, const float* A, const float* W, const SplitW& Ws, const float* bias, const float* resid,
           float* C, int M, int N, int K, hipStream_t s) {
-  static const bool wide = [] { const char* e = getenv("FDMI_GEMM_WIDE"); return e && atoi(e) != 0; }();
-  // experiment: 128 x 384 tiles for the plain GEMMs too; all token buffers hold whole 128-row tiles (ensure_ws)
-  if (wide && m->precision == FD_PREC_F16X3 && !resid &&
+  // 128 x 384 tiles where the shape fits; all token buffers hold whole 128-row tiles (ensure_ws), so the
+  // row count is rounded up for it
+  if (m->precision == FD_PREC_F16X3 && !resid &&
       launch_gemm_f16x3_wide(epi, A, Ws.p, Ws.scale, bias, C, (M + 127) / 128 * 128, N, K, s))
     return;
   if (m->precision == FD_PREC_F16X3) launch_gemm_f16x3(epi, A, Ws.p, Ws.scale, bias, resid, C, M, N, K, s);

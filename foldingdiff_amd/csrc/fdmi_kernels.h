@@ -36,7 +36,8 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
                           const float* gamma, const float* beta, float eps, float* C, int M, int N, int K,
                           hipStream_t s);
 
-// Plain-epilogue GEMM on the 128 x 384 tiling of the LN-fused kernel (experiment; false if the shape does not fit).
+// Plain-epilogue (bias | bias + GELU) GEMM on the 128 x 384 tiling of the LN-fused kernel; false if disabled
+// (FDMI_GEMM_WIDE=0) or the shape does not fit (N % 384, M % 128, K % 64) -- callers fall back to launch_gemm_f16x3.
 bool launch_gemm_f16x3_wide(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias, float* C,
                             int M, int N, int K, hipStream_t s);
 

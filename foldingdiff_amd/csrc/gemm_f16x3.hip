@@ -616,8 +616,8 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
 // DBG (ablation builds via FDMI_LN_DBG, results wrong by design): 1 = no residual loads, 2 = no output
 // stores, 3 = no LayerNorm reductions.
 // PLAIN >= 0: the same 128 x 384 tiling with a plain bias (EPI_BIAS) / bias + GELU (EPI_BIAS_GELU) epilogue for
-// N a multiple of 384 (QKV, FFN-up, head dense1: "wide tile" experiment FDMI_GEMM_WIDE) -- each A panel is
-// split 3x less often than with 128-column tiles.
+// N a multiple of 384 (QKV, FFN-up, head dense1; launch_gemm_f16x3_wide) -- each A panel is split 3x less
+// often than with 128-column tiles and a wave issues 18 MFMAs per 10 fragment fetches instead of 12 per 8.
 template <int DBG, int PLAIN = -1>
 __global__ __launch_bounds__(512) void gemm_f16x3_ln_kernel(GemmLnArgs p) {
   constexpr int BM = 128, BN = 384, BK = 32, RQ = 9, NTHR = 512, NT = 3;
@@ -924,11 +924,14 @@ bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const f
   return true;
 }
 
-// "Wide tile" variant of the plain GEMMs (experiment knob FDMI_GEMM_WIDE=1, see gemm_f16x3_ln_kernel): false
-// when the shape does not fit (N % 384, M % 128, K % 64).
+// "Wide tile" variant of the plain GEMMs (see gemm_f16x3_ln_kernel; default, FDMI_GEMM_WIDE=0 turns it off:
+// measured QKV 199 -> 191 us, FFN-up 153 -> 140, head 83 -> 75): false when disabled or the shape does not
+// fit (N % 384, M % 128, K % 64).
 bool launch_gemm_f16x3_wide(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias, float* C,
                             int M, int N, int K, hipStream_t s) {
-  if ((epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU) || N % 384 != 0 || K % 64 != 0 || K < 128 || M % 128 != 0)
+  static const int enabled = env_int("FDMI_GEMM_WIDE", 1);
+  if (!enabled || (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU) || N % 384 != 0 || K % 64 != 0 || K < 128 ||
+      M % 128 != 0)
     return false;
   constexpr int smem = 2 * (128 + 384) * 9 * 16 + 2 * 128 * 5 * 4;
   static bool attr_set = false;
@@ -1000,6 +1003,7 @@ void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_sca
   static const int bm = env_int("FDMI_GEMM_BM", 256) == 128 ? 128 : 256;
   const float a_scale = 16.0f;  // |a| < 4094 stays finite in fp16; lo of |a| > 0.008 is a normal fp16
   GemmSplitArgs p{A, static_cast<const u32x4*>(Wp), bias, resid, C, M, N, K, a_scale, 1.0f / (a_scale * w_scale)};
+  if (dbg == 0 && !resid && launch_gemm_f16x3_wide(epilogue, A, Wp, w_scale, bias, C, M, N, K, s)) return;
   static const int persist = env_int("FDMI_GEMM_PERSIST", 1);
   if (persist && dbg == 0 && (K / 32) % 2 == 0 && K >= 128) {
     static const int pbm = env_int("FDMI_GEMM_PBM", 256);  // rows per persistent workgroup: 256 (8 waves) | 128 (4 waves, 2 per CU)
