@@ -240,3 +240,28 @@ def test_forward_noising_matches_reference_bitwise():
     assert np.array_equal(it["corrupted"].numpy(), g["rand_corrupted"])
     with pytest.raises(NotImplementedError):
         sampling.get_reconstruction_error(None, ds)
+
+
+def test_pdb_writer_fixed_columns(tmp_path):
+    """write_coords_to_pdb (foldingdiff/angles_and_coords.py:187-253): PDB ATOM records in the format
+    specification's fixed columns, GLY backbone atoms N / CA / C on chain A, round trip within 5e-4 A."""
+    from foldingdiff_amd import angles_and_coords as ac
+    rng = np.random.default_rng(3)
+    coords = rng.standard_normal((3 * 130, 3)) * 40
+    f = ac.write_coords_to_pdb(coords, str(tmp_path / "x.pdb"))
+    lines = open(f).read().splitlines()
+    assert len(lines) == 390 and all(len(l) == 80 for l in lines)
+    l = lines[4]  # second residue, CA
+    assert l[:6] == "ATOM  " and int(l[6:11]) == 5 and l[12:16] == " CA " and l[17:20] == "GLY" and l[21] == "A"
+    assert int(l[22:26]) == 2 and l[54:60] == "  1.00" and l[60:66] == "  5.00" and l[76:78] == " C"
+    assert lines[3][12:16] == " N  " and lines[3][76:78] == " N" and lines[389][22:26] == " 130"
+    assert np.abs(ac.read_pdb_backbone(f) - coords).max() <= 5.001e-4
+    with pytest.raises(AssertionError):
+        ac.write_coords_to_pdb(coords[:4], str(tmp_path / "y.pdb"))
+    # column selection rules of create_new_chain_nerf (no device needed until the build)
+    vals, keep = ac._select(np.zeros((3, 4), np.float32), ["phi", "psi", "omega", "0C:1N"], None, None)
+    assert keep == ["phi", "psi", "omega", "0C:1N"]
+    with pytest.raises(ValueError):
+        ac._select(np.zeros((3, 4), np.float32), ["phi", "psi", "omega", "chi1"], None, None)
+    with pytest.raises(AssertionError):
+        ac._select(np.zeros((3, 2), np.float32), ["phi", "psi"], None, None)
