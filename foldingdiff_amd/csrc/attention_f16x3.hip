@@ -76,7 +76,8 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
 // OCC = workgroups per CU the register allocation is capped for (2: up to 256 VGPRs, no spills;
 // 3: 168 VGPRs, T = 4 spills ~100 dwords -- experiment knob FDMI_ATTN_OCC, 53.5 KB of LDS per workgroup
 // allows three).
-template <int T, bool REL, int OCC>
+// TC = S^T tiles (32 keys each) per softmax chunk, T % TC == 0 (TC = T: the whole key tile at once).
+template <int T, bool REL, int OCC, int TC = T>
 __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float* __restrict__ qkv,
                                                                const u32x4* __restrict__ demb, float r_scale,
                                                                const int* __restrict__ lens, float* __restrict__ ctx,
@@ -176,164 +177,169 @@ __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float*
     __syncthreads();
     if (!active) continue;
 
-    // band row of R tile q, column l31:  m = (maxpos-1) - (LP-1) + LP*(qg-kt) + 32*wq + 32q + l31.
-    // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos), so
-    // the index is clamped instead of predicated (keeps the loads unconditional).  (Prefetching
-    // one band tile ahead was measured: no gain, and the extra registers push the kernel into spills.)
-    auto load_band = [&](u32x4 (&e)[4], int q) {
-      int m = (maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * q;
-      m = m < 0 ? 0 : (m > 2 * (maxpos - 1) ? 2 * (maxpos - 1) : m);
-      const u32x4* row = demb + (size_t)m * 8;  // 128-byte image: units 0-3 hi d0-31, 4-7 lo
-      e[0] = row[half]; e[1] = row[2 + half]; e[2] = row[4 + half]; e[3] = row[6 + half];
-    };
-    // S^T tiles: rows = keys r0 + 32t + rowmap(r, half), cols = queries l0 + l31
-    f32x16 sacc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-      const unsigned char* row = Kh + (size_t)(32 * t + l31) * KROW;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 32 * c + 16 * half));
-        const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 64 + 32 * c + 16 * half));
-        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
-        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
-        sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
-      }
-    }
-    // Scores stay RAW MFMA sums u (scaled by QS*KS): the factor log2(e) / sqrt(head size) / (QS*KS)
-    // that takes them to the log2 domain is applied inside the exponent fma of the softmax, and the
-    // band values are brought to the same raw scale by the (power-of-two, exact) ratio of the scales
-    // inside the accumulate fma -- no separate scaling pass over scores or band tiles.
+    // The 32*T keys of the tile are processed TC S^T tiles (32*TC keys) at a time with the same online
+    // softmax that links key tiles: TC < T trades a little recomputation (one band tile per extra chunk,
+    // one rescale of the O accumulator) for 16*(T-TC) fewer live score registers.
     constexpr float S_SCALE = kLog2eOverSqrtD / (QS * KS);
-    if constexpr (REL) {
-      // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31 (band origin: this
-      // wave's row block).  S^T tile t element (key kl, query ql)
-      // needs band column j = ql - kl + 31 of the tile pair (q = T-1-t, q+1):  j < 32 -> tile q,
-      // else tile q+1 column j-32.
-      // band row of R tile q, column l31:  m = (maxpos-1) - (LP-1) + LP*(qg-kt) + 32*wq + 32q + l31.
-      // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos), so
-      // the index is clamped instead of predicated (keeps the loads unconditional).
-      const float R_RATIO = r_scale;  // KS / table scale: band sums -> the raw scale of the scores
-#pragma unroll
-      for (int q = 0; q <= T; ++q) {
-        u32x4 ecur[4];
-        load_band(ecur, q);
-        f32x16 racc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const f16x8 eh = __builtin_bit_cast(f16x8, ecur[c]);
-          const f16x8 el = __builtin_bit_cast(f16x8, ecur[2 + c]);
-          racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], eh, racc, 0, 0, 0);
-          racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], el, racc, 0, 0, 0);
-          racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[c], eh, racc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // scratch row = query l31 (this lane).  Band column j = l31 - kl + 31 of the tile PAIR
-        // (q, q+1) lives in tile q for j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise:
-        // both cases read scratch column j & 31, so one branch-free set of 16 reads serves the two
-        // S^T tiles that use band tile q (selects, no exec-mask branches around LDS reads).
-        float gth[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-          gth[r] = Rw[l31 * RLD + ((l31 - kl + 31) & 31)];
-        }
-        if (q < T) {  // low tile of S^T tile t = T-1-q
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            sacc[T - 1 - q][r] = __builtin_fmaf((l31 <= kl) ? gth[r] : 0.f, R_RATIO, sacc[T - 1 - q][r]);
-          }
-        }
-        if (q > 0) {  // high tile of S^T tile t = T-q
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            sacc[T - q][r] = __builtin_fmaf((l31 > kl) ? gth[r] : 0.f, R_RATIO, sacc[T - q][r]);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one
-    // query's scores.  Key tiles without masked / padding keys (wave-uniform test) skip the mask ops.
-    float mt = -INFINITY;
-    if (r0 + LP <= len) {
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
-    } else {
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float sc = sacc[t][r];
-          if (key >= len) sc += kMaskLog2 / S_SCALE;   // (1 - mask) * -10000   (modelling.py:452), raw scale
-          if (key >= L) sc = -INFINITY;      // tile padding: not a key at all
-          sacc[t][r] = sc;
-          mt = fmaxf(mt, sc);
-        }
-    }
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);                    // running maximum, raw scale
-    const float alpha = exp2_neg((m_run - m_new) * S_SCALE);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
-    // p' = PS * 2^((u - m) * S_SCALE): the fp16-split scale PS = 2^10 rides in the exponent
-    const float nm = __builtin_fmaf(-m_new, S_SCALE, 10.0f);
-    static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pexp = exp2_neg(__builtin_fmaf(sacc[t][r], S_SCALE, nm));
-        sacc[t][r] = pexp;
-        psum += pexp;
-      }
-    psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;   // carries the factor PS
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
-    // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],
-    //                   B[position][n = query l31] = P[query][key(c,half,j)] = sacc[t][8c + j],
-    //                   key(c, half, j) = 32t + 16c + 8(j>>2) + 4*half + (j&3)   (the C/D row map)
     const unsigned char* vrow = Vh + (size_t)l31 * VROW;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t0 = 0; t0 < T; t0 += TC) {
+      // chunks made only of keys >= len contribute exactly 0 (see above); chunk 0 always has key 0 < len
+      if (r0 + 32 * t0 >= len) break;
+      // band row of R tile q, column l31:  m = (maxpos-1) - (LP-1) + LP*(qg-kt) + 32*wq + 32q + l31.
+      // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos), so
+      // the index is clamped instead of predicated (keeps the loads unconditional).  (Prefetching
+      // one band tile ahead was measured: no gain, and the extra registers push the kernel into spills.)
+      auto load_band = [&](u32x4 (&e)[4], int q) {
+        int m = (maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * q;
+        m = m < 0 ? 0 : (m > 2 * (maxpos - 1) ? 2 * (maxpos - 1) : m);
+        const u32x4* row = demb + (size_t)m * 8;  // 128-byte image: units 0-3 hi d0-31, 4-7 lo
+        e[0] = row[half]; e[1] = row[2 + half]; e[2] = row[4 + half]; e[3] = row[6 + half];
+      };
+      // S^T tiles of this chunk: rows = keys r0 + 32(t0+t) + rowmap(r, half), cols = queries l0 + l31.
+      // Scores stay RAW MFMA sums u (scaled by QS*KS): the factor log2(e) / sqrt(head size) / (QS*KS)
+      // that takes them to the log2 domain is applied inside the exponent fma of the softmax, and the
+      // band values are brought to the same raw scale by the (power-of-two, exact) ratio of the scales
+      // inside the accumulate fma -- no separate scaling pass over scores or band tiles.
+      f32x16 sacc[TC];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        f16x8 ph, pl;
+      for (int t = 0; t < TC; ++t) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xs = sacc[t][8 * c + j];  // PS * unnormalised probability (<= PS): ready for the fp16 split
-          const _Float16 hv = (_Float16)xs;
-          ph[j] = hv;
-          pl[j] = (_Float16)(xs - (float)hv);
+        for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+        const unsigned char* row = Kh + (size_t)(32 * (t0 + t) + l31) * KROW;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 32 * c + 16 * half));
+          const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row + 64 + 32 * c + 16 * half));
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
         }
-        // V operand: keys 32t + 16c + 4half + {0..3} and + 8 : two 8-byte reads per plane
-        const int kb = 2 * (32 * t + 16 * c + 4 * half);
-        const u32x2 vh0 = *reinterpret_cast<const u32x2*>(vrow + kb);
-        const u32x2 vh1 = *reinterpret_cast<const u32x2*>(vrow + kb + 16);
-        const u32x2 vl0 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb);
-        const u32x2 vl1 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb + 16);
-        const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
-        const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
-        const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc, 0, 0, 0);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc, 0, 0, 0);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc, 0, 0, 0);
       }
+      if constexpr (REL) {
+        // R tile q: rows = queries rowmap(r, half), cols = band index 32q + l31 (band origin: this
+        // wave's row block).  S^T tile t (of the key tile) element (key kl, query ql) needs band column
+        // j = ql - kl + 31 of the tile pair (q = T-1-t, q+1):  j < 32 -> tile q, else tile q+1 column j-32.
+        // The chunk's tiles t0 .. t0+TC-1 therefore use band tiles q = T-t0-TC .. T-t0.
+        const float R_RATIO = r_scale;  // KS / table scale: band sums -> the raw scale of the scores
+#pragma unroll
+        for (int qq = 0; qq <= TC; ++qq) {
+          u32x4 ecur[4];
+          load_band(ecur, T - t0 - TC + qq);
+          f32x16 racc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const f16x8 eh = __builtin_bit_cast(f16x8, ecur[c]);
+            const f16x8 el = __builtin_bit_cast(f16x8, ecur[2 + c]);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], eh, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], el, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[c], eh, racc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // scratch row = query l31 (this lane).  Band column j = l31 - kl + 31 of the tile PAIR
+          // (q, q+1) lives in tile q for j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise:
+          // both cases read scratch column j & 31, so one branch-free set of 16 reads serves the two
+          // S^T tiles that use band tile q (selects, no exec-mask branches around LDS reads).
+          float gth[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            gth[r] = Rw[l31 * RLD + ((l31 - kl + 31) & 31)];
+          }
+          if (qq < TC) {  // low part: chunk tile TC-1-qq
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              sacc[TC - 1 - qq][r] = __builtin_fmaf((l31 <= kl) ? gth[r] : 0.f, R_RATIO, sacc[TC - 1 - qq][r]);
+            }
+          }
+          if (qq > 0) {  // high part: chunk tile TC-qq
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              sacc[TC - qq][r] = __builtin_fmaf((l31 > kl) ? gth[r] : 0.f, R_RATIO, sacc[TC - qq][r]);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one
+      // query's scores.  Chunks without masked / padding keys (wave-uniform test) skip the mask ops.
+      float mt = -INFINITY;
+      if (r0 + 32 * (t0 + TC) <= len) {
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = r0 + 32 * (t0 + t) + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float sc = sacc[t][r];
+            if (key >= len) sc += kMaskLog2 / S_SCALE;   // (1 - mask) * -10000   (modelling.py:452), raw scale
+            if (key >= L) sc = -INFINITY;                // tile padding: not a key at all
+            sacc[t][r] = sc;
+            mt = fmaxf(mt, sc);
+          }
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float m_new = fmaxf(m_run, mt);                    // running maximum, raw scale
+      const float alpha = exp2_neg((m_run - m_new) * S_SCALE);  // first chunk: 2^-inf = 0 (accumulators are 0 anyway)
+      // p' = PS * 2^((u - m) * S_SCALE): the fp16-split scale PS = 2^10 rides in the exponent
+      const float nm = __builtin_fmaf(-m_new, S_SCALE, 10.0f);
+      static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pexp = exp2_neg(__builtin_fmaf(sacc[t][r], S_SCALE, nm));
+          sacc[t][r] = pexp;
+          psum += pexp;
+        }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;   // carries the factor PS
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],
+      //                   B[position][n = query l31] = P[query][key(c,half,j)] = sacc[t][8c + j],
+      //                   key(c, half, j) = 32(t0+t) + 16c + 8(j>>2) + 4*half + (j&3)   (the C/D row map)
+#pragma unroll
+      for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f16x8 ph, pl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xs = sacc[t][8 * c + j];  // PS * unnormalised probability (<= PS): ready for the fp16 split
+            const _Float16 hv = (_Float16)xs;
+            ph[j] = hv;
+            pl[j] = (_Float16)(xs - (float)hv);
+          }
+          // V operand: keys 32(t0+t) + 16c + 4half + {0..3} and + 8 : two 8-byte reads per plane
+          const int kb = 2 * (32 * (t0 + t) + 16 * c + 4 * half);
+          const u32x2 vh0 = *reinterpret_cast<const u32x2*>(vrow + kb);
+          const u32x2 vh1 = *reinterpret_cast<const u32x2*>(vrow + kb + 16);
+          const u32x2 vl0 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb);
+          const u32x2 vl1 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb + 16);
+          const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
+          const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
+          const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc, 0, 0, 0);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc, 0, 0, 0);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc, 0, 0, 0);
+        }
+    }
   }
   if (!active) return;
   // ctx[query][h*32 + d] = O^T[d][query] / l_run : this lane owns query l0 + l31 and, per register
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float*
   }
 }
 
-template <int T, bool REL, int OCC>
+template <int T, bool REL, int OCC, int TC = T>
 static void launch_occ(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
                      int maxpos, hipStream_t s) {
   constexpr int LP = 32 * T;
@@ -357,13 +363,13 @@ static void launch_occ(const float* qkv, const void* demb, float r_scale, const 
                       (REL ? sizeof(float) * 4 * HPB * 32 * RLD : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL, OCC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL, OCC, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int hgroups = (H + HPB - 1) / HPB;
   const int nqg = (L + LP - 1) / LP;
-  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL, OCC>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
+  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL, OCC, TC>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
                      static_cast<const u32x4*>(demb), r_scale, lens, ctx, L, H, maxpos);
 }
 
@@ -371,6 +377,14 @@ template <int T, bool REL>
 static void launch_t(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
                      int maxpos, hipStream_t s) {
   static const int occ = [] { const char* e = getenv("FDMI_ATTN_OCC"); return e ? atoi(e) : 2; }();
+  static const int chunk = [] { const char* e = getenv("FDMI_ATTN_CHUNK"); return e ? atoi(e) : 0; }();
+  if constexpr (T == 4) {
+    if (chunk == 2) {  // 64-key softmax chunks: 32 fewer live registers (experiment)
+      if (occ == 3) launch_occ<T, REL, 3, 2>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
+      else launch_occ<T, REL, 2, 2>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
+      return;
+    }
+  }
   if (occ == 3) launch_occ<T, REL, 3>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
   else launch_occ<T, REL, 2>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
 }
