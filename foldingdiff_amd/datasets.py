@@ -120,43 +120,34 @@ class NoisedAnglesDataset:
         (foldingdiff/datasets.py:801-886; SURVEY 8f N3 -- the input of the partial-noise
         reconstruction path).  ``use_t_val`` fixes t (clipped to [0, timesteps-1]); otherwise t is
         the exhaustive index or one ``torch.randint`` draw, exactly as in the reference."""
-        assert 0 <= index < len(self), f"Index {index} out of bounds for {len(self)}"
-        if self.exhaustive_timesteps:
-            item_index, time_index = index // self.timesteps, index % self.timesteps
-            item = self.dset.__getitem__(item_index, ignore_zero_center=ignore_zero_center)
-        else:
-            item = self.dset.__getitem__(index, ignore_zero_center=ignore_zero_center)
-        if self.dset_key is not None:
-            assert isinstance(item, dict)
-            vals = item[self.dset_key].clone()
-        else:
-            vals = item.clone()
-        assert isinstance(vals, torch.Tensor)
+        if not 0 <= index < len(self):
+            raise AssertionError(f"Index {index} out of bounds for {len(self)}")
+        which, step = (divmod(index, self.timesteps) if self.exhaustive_timesteps else (index, None))
+        item = self.dset.__getitem__(which, ignore_zero_center=ignore_zero_center)
+        x0 = (item[self.dset_key] if self.dset_key is not None else item).clone()
+        assert isinstance(x0, torch.Tensor)
+        # t: caller-fixed (clipped), the exhaustive index, or ONE draw from the global generator -- the draw
+        # comes before the noise draw, as in the reference (the order fixes the random stream)
         if use_t_val is not None:
             assert not self.exhaustive_timesteps, "Cannot use specific t in exhaustive mode"
             t = torch.from_numpy(np.clip(np.array([use_t_val]), 0, self.timesteps - 1)).long()
-        elif self.exhaustive_timesteps:
-            t = torch.tensor([time_index]).long()
+        elif step is not None:
+            t = torch.tensor([step]).long()
         else:
             t = torch.randint(0, self.timesteps, (1,)).long()
-        sqrt_alphas_cumprod_t = self.alpha_beta_terms["sqrt_alphas_cumprod"][t.item()]
-        sqrt_one_minus_alphas_cumprod_t = self.alpha_beta_terms["sqrt_one_minus_alphas_cumprod"][t.item()]
-        noise = self.sample_noise(vals)
-        noised_vals = sqrt_alphas_cumprod_t * vals + sqrt_one_minus_alphas_cumprod_t * noise
-        angular_idx = np.where(self.dset.feature_is_angular[self.dset_key])[0]
-        noised_vals[:, angular_idx] = utils.modulo_with_wrapped_range(noised_vals[:, angular_idx], -np.pi, np.pi)
-        retval = {
-            "corrupted": noised_vals,
-            "t": t,
-            "known_noise": noise,
-            "sqrt_alphas_cumprod_t": sqrt_alphas_cumprod_t,
-            "sqrt_one_minus_alphas_cumprod_t": sqrt_one_minus_alphas_cumprod_t,
-        }
-        if isinstance(item, dict):
-            assert item.keys().isdisjoint(retval.keys())
-            item.update(retval)
-            return item
-        return retval
+        terms = self.alpha_beta_terms
+        keep, spread = terms["sqrt_alphas_cumprod"][t.item()], terms["sqrt_one_minus_alphas_cumprod"][t.item()]
+        eps = self.sample_noise(x0)                      # shape-only use of x0
+        x_t = keep * x0 + spread * eps                    # q(x_t | x_0)
+        wrap_cols = np.where(self.dset.feature_is_angular[self.dset_key])[0]
+        x_t[:, wrap_cols] = utils.modulo_with_wrapped_range(x_t[:, wrap_cols], -np.pi, np.pi)
+        extra = {"corrupted": x_t, "t": t, "known_noise": eps,
+                 "sqrt_alphas_cumprod_t": keep, "sqrt_one_minus_alphas_cumprod_t": spread}
+        if not isinstance(item, dict):
+            return extra
+        assert item.keys().isdisjoint(extra.keys())
+        item.update(extra)
+        return item
 
     def sample_noise(self, vals: torch.Tensor) -> torch.Tensor:
         """N(0, 1) from the global CPU generator (same draw as the reference, so a
