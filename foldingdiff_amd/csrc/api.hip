@@ -746,6 +746,7 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
                   void* hip_stream) {
   if (int rc = check_shape(m, B, L, t_start)) return rc;
   if (!x_init_dev || !lens_dev || !out_dev) return fail(FD_E_INVALID, "null argument");
+  if (full_history < 0) return fail(FD_E_INVALID, "full_history = %d", full_history);
   HIP_TRY(hipSetDevice(m->device));
   if (int rc = ensure_ws(m, B, L)) return rc;
   if (m->use_graph)
@@ -762,6 +763,7 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
   dyn.seed = seed;
   dyn.seq_offset = seq_offset;
   dyn.t_start = t_start;
+  dyn.hist_every = full_history;
   hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, s, w.dyn, dyn);
   if (int rc = set_t(m, s, t_start)) return rc;
   const int nsteps = t_start + 1;
@@ -785,10 +787,13 @@ int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int 
               uint64_t seed, float* out, int full_history) {
   if (int rc = check_shape(m, B, L, t_start)) return rc;
   if (!x_init || !lens || !out) return fail(FD_E_INVALID, "null argument");
+  if (full_history < 0) return fail(FD_E_INVALID, "full_history = %d", full_history);
   if (int rc = check_lens(lens, B, L)) return rc;
   HIP_TRY(hipSetDevice(m->device));
   const size_t n = (size_t)B * L * m->cfg.n_features;
   const size_t nsteps = (size_t)t_start + 1;
+  // rows of `out`: 1 (final only), every state, or every full_history-th state plus the final one
+  const size_t out_rows = full_history ? (nsteps + full_history - 1) / full_history : 1;
   float *d_x = nullptr, *d_noise = nullptr, *d_out = nullptr;
   int* d_lens = nullptr;
   int rc = FD_OK;
@@ -806,7 +811,7 @@ int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int 
   } while (0)
   TRY_CLEAN(hipMalloc((void**)&d_x, n * 4));
   TRY_CLEAN(hipMalloc((void**)&d_lens, (size_t)B * 4));
-  TRY_CLEAN(hipMalloc((void**)&d_out, (full_history ? nsteps : 1) * n * 4));
+  TRY_CLEAN(hipMalloc((void**)&d_out, out_rows * n * 4));
   TRY_CLEAN(hipMemcpy(d_x, x_init, n * 4, hipMemcpyHostToDevice));
   TRY_CLEAN(hipMemcpy(d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice));
   if (noise) {
@@ -819,7 +824,7 @@ int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int 
     return rc;
   }
   TRY_CLEAN(hipStreamSynchronize(m->stream));
-  TRY_CLEAN(hipMemcpy(out, d_out, (full_history ? nsteps : 1) * n * 4, hipMemcpyDeviceToHost));
+  TRY_CLEAN(hipMemcpy(out, d_out, out_rows * n * 4, hipMemcpyDeviceToHost));
 #undef TRY_CLEAN
   cleanup();
   return FD_OK;

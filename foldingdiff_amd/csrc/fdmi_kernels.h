@@ -76,7 +76,7 @@ struct UpdateDyn {
   unsigned long long seed;
   long long seq_offset;
   int t_start;
-  int pad_;
+  int hist_every;        // keep every k-th state (and the final one) in `hist`; <= 1: every state
 };
 struct UpdateArgs {
   const UpdateDyn* dyn;  // device pointer; when non-null it overrides noise/hist/seed/seq_offset/t_start

@@ -353,9 +353,10 @@ __global__ __launch_bounds__(256) void head_update_kernel(UpdateArgs a) {
   float* hist = a.hist;
   unsigned long long seed = a.seed;
   long long seq_offset = a.seq_offset;
-  int t_start = a.t_start;
+  int t_start = a.t_start, hist_every = 1;
   if (a.dyn) {
     noise = a.dyn->noise; hist = a.dyn->hist; seed = a.dyn->seed; seq_offset = a.dyn->seq_offset; t_start = a.dyn->t_start;
+    hist_every = a.dyn->hist_every > 1 ? a.dyn->hist_every : 1;
   }
   const float c1 = a.coef[t], bt = a.coef[a.T + t], c3 = a.coef[2 * a.T + t], sg = a.coef[3 * a.T + t];
   // model_mean = sqrt_recip_alphas_t * (x - betas_t * eps / sqrt_one_minus_alphas_cumprod_t)   (sampling.py:62-67)
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(256) void head_update_kernel(UpdateArgs a) {
   }
   if ((a.angle_mask >> lane) & 1u) xn = wrap_pi(xn);
   a.x_out[o] = xn;
-  if (hist) hist[(size_t)(t_start - t) * a.M * F + o] = xn;
+  if (hist && ((t_start - t + 1) % hist_every == 0 || t == 0))  // state j = t_start - t goes to row j / hist_every
+    hist[(size_t)((t_start - t) / hist_every) * a.M * F + o] = xn;
 }
 
 template <int NV>
@@ -392,9 +394,10 @@ __global__ __launch_bounds__(256) void head_update16_kernel(UpdateArgs a) {
   float* hist = a.hist;
   unsigned long long seed = a.seed;
   long long seq_offset = a.seq_offset;
-  int t_start = a.t_start;
+  int t_start = a.t_start, hist_every = 1;
   if (a.dyn) {
     noise = a.dyn->noise; hist = a.dyn->hist; seed = a.dyn->seed; seq_offset = a.dyn->seq_offset; t_start = a.dyn->t_start;
+    hist_every = a.dyn->hist_every > 1 ? a.dyn->hist_every : 1;
   }
   float c1 = 0.f, btc = 0.f, c3 = 1.f, sg = 0.f;
   if (a.x_out) { c1 = a.coef[t]; btc = a.coef[a.T + t]; c3 = a.coef[2 * a.T + t]; sg = a.coef[3 * a.T + t]; }
@@ -431,7 +434,8 @@ __global__ __launch_bounds__(256) void head_update16_kernel(UpdateArgs a) {
         }
         if ((a.angle_mask >> k) & 1u) xn = wrap_pi(xn);
         a.x_out[o] = xn;
-        if (hist) hist[(size_t)(t_start - t) * a.M * F + o] = xn;
+        if (hist && ((t_start - t + 1) % hist_every == 0 || t == 0))  // state j = t_start - t goes to row j / hist_every
+    hist[(size_t)((t_start - t) / hist_every) * a.M * F + o] = xn;
       }
     }
   }

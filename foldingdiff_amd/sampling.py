@@ -83,11 +83,15 @@ def p_sample_loop(
     is_angle: Union[bool, List[bool]] = [False, True, True, True],
     disable_pbar: bool = False,
     final_only: bool = False,
+    history_every: int = 1,
 ) -> torch.Tensor:
     """Run the whole reverse process from ``noise``.  Returns a CPU tensor of shape
     (timesteps, batch_size, seq_len, n_ft) -- entry j is the state after step
     t = timesteps-1-j, last entry = the sample -- or (1, batch, seq_len, n_ft) holding
-    only the final sample when ``final_only`` (extension; skips the history copy)."""
+    only the final sample when ``final_only`` (extension; skips the history copy), or, with
+    ``history_every=k > 1`` (extension), (ceil(timesteps / k), ...): every k-th state
+    (j = k-1, 2k-1, ...) with the sample in the last entry -- the history is thinned on the device."""
+    assert history_every >= 1
     assert len(betas) == timesteps, f"{len(betas)} betas for {timesteps} timesteps"
     if not isinstance(is_angle, bool):
         assert len(is_angle) == noise.shape[-1]
@@ -105,10 +109,11 @@ def p_sample_loop(
         seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
     else:
         raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
-    out = np.empty(((1 if final_only else timesteps), B, L, F), dtype=np.float32)
+    rows = 1 if final_only else -(-timesteps // history_every)
+    out = np.empty((rows, B, L, F), dtype=np.float32)
     _binding.check(lib.fd_sample(h, x0.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, L,
                                  timesteps - 1, zptr, C.c_uint64(seed), out.ctypes.data_as(C.c_void_p),
-                                 0 if final_only else 1))
+                                 0 if final_only else history_every))
     return torch.from_numpy(out)
 
 
@@ -122,13 +127,14 @@ def sample_on_device(
     seed: int = 0,
     seq_offset: int = 0,
     noise: Optional[torch.Tensor] = None,
-    full_history: bool = False,
+    full_history: Union[bool, int] = False,
     t_start: Optional[int] = None,
     sync: bool = True,
 ) -> torch.Tensor:
     """Device-resident variant: ``x_init`` [B, L, F] float32 and ``lens`` [B] int32 are
     CUDA tensors, the result is a CUDA tensor ([B, L, F], or [t_start+1, B, L, F] with
-    ``full_history``); nothing touches the host.  Under a non-default torch stream the work is
+    ``full_history``, or [ceil((t_start+1)/k), B, L, F] with ``full_history=k > 1``: every k-th state plus
+    the final one); nothing touches the host.  Under a non-default torch stream the work is
     enqueued on that stream (asynchronous, stream-ordered).  Under torch's default (null)
     stream it runs on the model's own stream: pending torch work is waited for first and,
     unless ``sync=False``, the call returns after the sampler finished."""
@@ -138,7 +144,9 @@ def sample_on_device(
     B, L, F = x_init.shape
     T = len(betas)
     t_start = T - 1 if t_start is None else t_start
-    shape = (t_start + 1, B, L, F) if full_history else (B, L, F)
+    hist = int(full_history)   # 0 final only, 1 every state, k every k-th state
+    assert hist >= 0
+    shape = (-(-(t_start + 1) // hist), B, L, F) if hist else (B, L, F)
     out = torch.empty(shape, dtype=torch.float32, device=x_init.device)
     nptr = None
     if noise is not None:
@@ -152,7 +160,7 @@ def sample_on_device(
     lib = _binding.load()
     _binding.check(lib.fd_sample_dev(
         h, C.c_void_p(x_init.data_ptr()), C.c_void_p(lens.data_ptr()), B, L, t_start, nptr, C.c_uint64(seed),
-        C.c_int64(seq_offset), C.c_void_p(out.data_ptr()), 1 if full_history else 0,
+        C.c_int64(seq_offset), C.c_void_p(out.data_ptr()), hist,
         None if own_stream else C.c_void_p(ts.cuda_stream)))
     if own_stream and sync:
         _binding.check(lib.fd_synchronize(h))
@@ -169,12 +177,14 @@ def sample(
     disable_pbar: bool = False,
     trim_to_length: bool = True,
     final_only: bool = False,
+    history_every: int = 1,
 ) -> List[np.ndarray]:
     """Sample ``n`` backbones per length in ``range(*sweep_lengths)`` (upper bound
     exclusive) -- or ``n`` backbones with lengths from ``train_dset.sample_length()``
     when ``sweep_lengths`` is None.  Returns one array per backbone of shape
     (timesteps, seq_len, fts); index -1 is the sample.  ``final_only=True`` (extension)
-    returns arrays of shape (1, seq_len, fts) and never materialises the history.
+    returns arrays of shape (1, seq_len, fts) and never materialises the history;
+    ``history_every=k`` (extension) keeps every k-th state plus the sample (``p_sample_loop``).
 
     ``train_dset`` needs ``sample_noise``, ``timesteps``, ``alpha_beta_terms``,
     ``feature_is_angular``, ``pad`` (and optionally ``sample_length``,
@@ -197,7 +207,7 @@ def sample(
         traj = p_sample_loop(
             model=model, lengths=these, noise=noise, timesteps=train_dset.timesteps,
             betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
-            disable_pbar=disable_pbar, final_only=final_only)
+            disable_pbar=disable_pbar, final_only=final_only, history_every=history_every)
         results.extend(traj[:, i, :l, :].numpy() for i, l in enumerate(these))
     inner = getattr(train_dset, "dset", None)
     offset = None

@@ -139,8 +139,11 @@ int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, in
  *   noise    [t_start+1][B][L][F] per-step N(0,1) draws, row i used at t = i
  *            (row 0 unused), or NULL => on-device Philox4x32-10 keyed by
  *            (seed, t, element) -- deterministic, but NOT torch's stream
- *   out      full_history ? [t_start+1][B][L][F] (row j = state after step
- *            t = t_start - j, i.e. the reference's stacked `imgs`) : [B][L][F]
+ *   out      full_history == 0: [B][L][F], the final sample only;
+ *            full_history == 1: [t_start+1][B][L][F] (row j = state after step t = t_start - j,
+ *            i.e. the reference's stacked `imgs`);
+ *            full_history == k > 1: [ceil((t_start+1)/k)][B][L][F] -- every k-th state (j = k-1,
+ *            2k-1, ...) and the final one in the last row (strided history)
  * The per-step loop is a captured hipGraph replayed t_start+1 times; the step
  * index lives on the device. */
 int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
