@@ -77,7 +77,9 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, float s
 // 3: 168 VGPRs, T = 4 spills ~100 dwords -- experiment knob FDMI_ATTN_OCC, 53.5 KB of LDS per workgroup
 // allows three).
 // TC = S^T tiles (32 keys each) per softmax chunk, T % TC == 0 (TC = T: the whole key tile at once).
-template <int T, bool REL, int OCC, int TC = T>
+// RB = scratch buffers per wave for the relative-key skew (2: consecutive band tiles alternate buffers, which
+// removes the write-after-read barrier between them -- untimed experiment, FDMI_ATTN_RBUF=2).
+template <int T, bool REL, int OCC, int TC = T, int RB = 1>
 __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float* __restrict__ qkv,
                                                                const u32x4* __restrict__ demb, float r_scale,
                                                                const int* __restrict__ lens, float* __restrict__ ctx,
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float*
   const float* base = seq + (h < H ? h : 0) * 32;
   const unsigned char* Kh = Ks + (size_t)hh * LP * KROW;
   const unsigned char* Vh = Vt + (size_t)hh * 32 * VROW;
-  float* Rw = Rs + wid * 32 * RLD;
+  float* Rw0 = Rs + wid * RB * 32 * RLD;
 
   // Q operand: lane (query l31, half) holds d = 16c + 8*half + j   (B of K.Q^T and A of Q.E^T alike)
   f16x8 qh[2], ql[2];
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float*
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[c], el, racc, 0, 0, 0);
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[c], eh, racc, 0, 0, 0);
           }
+          float* Rw = Rw0 + (RB == 2 ? (qq & 1) * 32 * RLD : 0);
 #pragma unroll
           for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -266,6 +269,14 @@ __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float*
               sacc[TC - qq][r] = __builtin_fmaf((l31 > kl) ? gth[r] : 0.f, R_RATIO, sacc[TC - qq][r]);
             }
           }
+          if constexpr (RB == 1) {  // the next band tile overwrites this scratch: reads first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+          // RB == 2: tile qq+1 goes to the other buffer; tile qq+2 is ordered behind these reads by the
+          // release/acquire pair of tile qq+1
+        }
+        if constexpr (RB == 2) {  // next chunk / key tile starts at buffer 0 again
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
@@ -355,21 +366,21 @@ __global__ __launch_bounds__(256 * HPB, OCC) void attn_f16x3_kernel(const float*
   }
 }
 
-template <int T, bool REL, int OCC, int TC = T>
+template <int T, bool REL, int OCC, int TC = T, int RB = 1>
 static void launch_occ(const float* qkv, const void* demb, float r_scale, const int* lens, float* ctx, int B, int L, int H,
                      int maxpos, hipStream_t s) {
   constexpr int LP = 32 * T;
   const size_t smem = (size_t)HPB * LP * KROW + (size_t)HPB * 32 * (4 * LP + 8) +
-                      (REL ? sizeof(float) * 4 * HPB * 32 * RLD : 0);
+                      (REL ? sizeof(float) * 4 * HPB * RB * 32 * RLD : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL, OCC, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_kernel<T, REL, OCC, TC, RB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int hgroups = (H + HPB - 1) / HPB;
   const int nqg = (L + LP - 1) / LP;
-  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL, OCC, TC>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
+  hipLaunchKernelGGL((attn_f16x3_kernel<T, REL, OCC, TC, RB>), dim3(B * hgroups * nqg), dim3(256 * HPB), smem, s, qkv,
                      static_cast<const u32x4*>(demb), r_scale, lens, ctx, L, H, maxpos);
 }
 
@@ -378,6 +389,13 @@ static void launch_t(const float* qkv, const void* demb, float r_scale, const in
                      int maxpos, hipStream_t s) {
   static const int occ = [] { const char* e = getenv("FDMI_ATTN_OCC"); return e ? atoi(e) : 2; }();
   static const int chunk = [] { const char* e = getenv("FDMI_ATTN_CHUNK"); return e ? atoi(e) : 0; }();
+  static const int rbuf = [] { const char* e = getenv("FDMI_ATTN_RBUF"); return e ? atoi(e) : 1; }();
+  if constexpr (T == 4 && REL) {
+    if (rbuf == 2) {  // double-buffered skew scratch (72 KB of LDS per workgroup, still two per CU)
+      launch_occ<T, REL, 2, T, 2>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
+      return;
+    }
+  }
   if constexpr (T == 4) {
     if (chunk == 2) {  // 64-key softmax chunks: 32 fewer live registers (experiment)
       if (occ == 3) launch_occ<T, REL, 3, 2>(qkv, demb, r_scale, lens, ctx, B, L, H, maxpos, s);
