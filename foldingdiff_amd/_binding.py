@@ -65,6 +65,8 @@ _SIGNATURES = {
     "fd_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fd_synchronize": (C.c_int, [_P]),
+    "fd_check_finite": (C.c_int, [_P]),
+    "fd_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "fd_last_error": (C.c_char_p, []),
 }
 

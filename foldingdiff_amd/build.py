@@ -16,8 +16,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfdmi.so")
-SOURCES = ["api.hip", "gemm_f32.hip", "gemm_f16x3.hip", "attention_f32.hip", "attention_f16x3.hip", "rowwise.hip", "nerf.hip"]
-HEADERS = [os.path.join(CSRC, "fdmi_kernels.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "fdmi.h")]
+SOURCES = ["api.hip", "gemm_f32.hip", "gemm_f16x3.hip", "gemm_img.hip", "attention_f32.hip", "attention_f16x3.hip",
+           "attention_img.hip", "rowwise.hip", "rowwise_img.hip", "nerf.hip"]
+HEADERS = [os.path.join(CSRC, "fdmi_kernels.h"), os.path.join(CSRC, "img_common.h"),
+           os.path.join(os.path.dirname(PKG_DIR), "include", "fdmi.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -59,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed ({r.returncode}):\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         return r
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB_PATH, objs):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])

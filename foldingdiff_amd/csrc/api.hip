@@ -50,17 +50,22 @@ struct SplitW {
 
 struct LayerDev {
   SplitW wqkv_s, wo_s, wi_s, wd_s, demb_s;
+  // row-image path: weight images padded to 384 rows, and the (static, power-of-two) scales of this layer's
+  // activation images -- derived from norm bounds of the weights at fd_finalize, so nothing can overflow fp16
+  SplitW wqk_i, wv_i, wo_i, wi_i, wd_i;
+  float *bqk = nullptr, *bv = nullptr;  // bias slices of bqkv
+  float s_h = 1.f, s_q = 1.f, s_k = 1.f, s_v = 1.f, s_a = 1.f, s_g = 1.f;
   float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
   float *wo = nullptr, *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr;
   float *wi = nullptr, *bi = nullptr, *wd = nullptr, *bd = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
 enum KClass {
-  KC_EMBED = 0, KC_GEMM_QKV, KC_ATTN, KC_GEMM_OUT, KC_LN1, KC_GEMM_UP, KC_GEMM_DOWN, KC_LN2, KC_GEMM_HEAD,
+  KC_EMBED = 0, KC_GEMM_QKV, KC_GEMM_V, KC_ATTN, KC_GEMM_OUT, KC_LN1, KC_GEMM_UP, KC_GEMM_DOWN, KC_LN2, KC_GEMM_HEAD,
   KC_HEAD_UPDATE, KC_ADVANCE, KC_COUNT
 };
 const char* const kClassName[KC_COUNT] = {
-    "embed_ln_time", "gemm_qkv", "attention", "gemm_attn_out", "layernorm_attn", "gemm_ffn_up",
+    "embed_ln_time", "gemm_qkv", "gemm_v", "attention", "gemm_attn_out", "layernorm_attn", "gemm_ffn_up",
     "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance"};
 
 struct Workspace {
@@ -68,15 +73,25 @@ struct Workspace {
   float *x = nullptr, *eps = nullptr, *h = nullptr, *qkv = nullptr, *ctx = nullptr, *a = nullptr, *tmp = nullptr,
         *g = nullptr, *z = nullptr;
   int* lens = nullptr;
-  int* t_dev = nullptr;
+  int* t_dev = nullptr;  // [0] step index; the row-image kernels also use [1] (see rowwise_img.hip)
   UpdateDyn* dyn = nullptr;
+  // row-image path (fdmi_kernels.h): images, per-(sequence, head) q / k / v^T, the token-row table
+  bool img = false;
+  int cap = 0, LPK = 0, LTOT = 0, NKT = 0;  // rows128 capacity = ceil128(B * ceil8(L)); key-tile geometry
+  unsigned char *himg = nullptr, *aimg = nullptr, *cimg = nullptr, *gimg = nullptr, *qbuf = nullptr, *kbuf = nullptr,
+                *vbuf = nullptr, *trash = nullptr;
+  int2* rowinfo = nullptr;
+  int *seq_row0 = nullptr, *nrow = nullptr, *dims = nullptr, *flag = nullptr;
   hipGraphExec_t graph = nullptr;
   int graph_fuse_ln = -2;  // option value the graph was captured with (-2: none)
+  uint64_t last_use = 0;
   void release() {
     if (graph) (void)hipGraphExecDestroy(graph);
     graph = nullptr;
     for (void* p : {(void*)x, (void*)eps, (void*)h, (void*)qkv, (void*)ctx, (void*)a, (void*)tmp, (void*)g, (void*)z,
-                    (void*)lens, (void*)t_dev, (void*)dyn})
+                    (void*)lens, (void*)t_dev, (void*)dyn, (void*)himg, (void*)aimg, (void*)cimg, (void*)gimg,
+                    (void*)qbuf, (void*)kbuf, (void*)vbuf, (void*)trash, (void*)rowinfo, (void*)seq_row0, (void*)nrow,
+                    (void*)dims, (void*)flag})
       if (p) (void)hipFree(p);
     *this = Workspace();
   }
@@ -103,13 +118,22 @@ struct fd_model {
   float *w_in = nullptr, *b_in = nullptr, *pos_emb = nullptr, *emb_g = nullptr, *emb_b = nullptr;
   std::vector<LayerDev> layers;
   float *hd_w1 = nullptr, *hd_b1 = nullptr, *hd_g = nullptr, *hd_b = nullptr, *hd_w2 = nullptr, *hd_b2 = nullptr;
-  SplitW hd_w1_s;
+  SplitW hd_w1_s, hd_w1_i;
+  float s_hfinal = 1.f, s_hg = 1.f;  // row-image scales: last hidden state, head activation
+  bool img = false;                  // FD_PREC_F16X3 runs on the row-image kernels
   float *coef = nullptr, *time_table = nullptr;
   // options
   int fuse_ln = -1;  // -1 auto: LN-fused GEMMs with fp16x3 (measured 9.37 vs 10.15 ms/step), not with fp32 (slower there)
   int use_graph = 1;
   int attn_f16 = 1;  // with FD_PREC_F16X3: attention on the fp16x3 kernel (0: keep the fp32-MFMA one)
-  Workspace ws;
+  int debug_stop = 0;  // row-image path: stop a step after this many launches (debug dumps; 0 = off)
+  int debug_layer = 0; // layer whose scales fd_debug_read uses
+  int varlen = 0;    // row-image path: only the first lens[b] positions of a sequence are token rows
+  // workspaces (buffers + captured graph) are kept per (B, L): sample_length()-driven sampling and ragged chunks
+  // alternate between a few shapes
+  std::vector<Workspace> cache;
+  uint64_t use_clock = 0;
+  Workspace ws;      // the current one (moved in and out of `cache`)
   // profiling
   int profile_every = 0;
   double prof_ms[KC_COUNT] = {0};
@@ -139,13 +163,13 @@ int upload(fd_model* m, float** out, const float* src, size_t n) {
 // W [N][K] fp32 -> [Npad128][K/32][hi x32 | lo x32] fp16 with w*scale = hi + lo (gemm_f16x3.hip).
 // scale = the power of two that puts max|w|*scale in [8192, 16384): every lo of a weight that
 // matters is a normal fp16 and nothing overflows.
-void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out, float* scale) {
+void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out, float* scale, int row_pad = 128) {
   float mx = 0.f;
   for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::fmax(mx, std::fabs(W[i]));
   float s = 1.f;
   if (mx > 0.f && std::isfinite(mx)) s = std::exp2(std::floor(std::log2(16384.0f / mx)));
   *scale = s;
-  const int npad = (N + 127) / 128 * 128, nk = K / 32;
+  const int npad = (N + row_pad - 1) / row_pad * row_pad, nk = K / 32;
   out->assign((size_t)npad * nk * 64, 0);
   for (int n = 0; n < N; ++n)
     for (int kt = 0; kt < nk; ++kt) {
@@ -160,9 +184,9 @@ void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out,
     }
 }
 
-int upload_split(fd_model* m, SplitW* dst, const float* W, int N, int K) {
+int upload_split(fd_model* m, SplitW* dst, const float* W, int N, int K, int row_pad = 128) {
   std::vector<uint16_t> img;
-  pack_split_weight(W, N, K, &img, &dst->scale);
+  pack_split_weight(W, N, K, &img, &dst->scale, row_pad);
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, img.size() * 2));
   m->allocs.push_back(p);
@@ -176,6 +200,49 @@ void free_weights(fd_model* m) {
   m->allocs.clear();
   m->layers.clear();
   m->finalized = false;
+}
+
+// ---- static scales of the activation images (row-image path).
+// Every image tensor gets the largest power of two s with  bound * s <= 30000 < fp16 max, where `bound` is a
+// guaranteed bound of |x| derived from the weights: a LayerNorm output obeys |y_i| <= max|gamma| sqrt(d) + max|beta|
+// and ||y||_2 <= max|gamma| sqrt(d) + ||beta||_2; a dense output |y W_j + b_j| <= ||y||_2 ||W_j||_2 + |b_j|; GELU and the
+// softmax-weighted average of V do not grow their argument.  Nothing overflows for ANY weights (trained outliers
+// included); elements far below the bound merely lose low bits of `lo` (absolute error bound * 2^-40).
+bool img_path_enabled() {
+  static const bool on = [] { const char* e = getenv("FDMI_IMG"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
+struct Bound {
+  float linf, l2;
+};
+float scale_for(float bound) {
+  if (!(bound > 0.f) || !std::isfinite(bound)) return 1.f;
+  float e = std::floor(std::log2(30000.0f / bound));
+  e = e < -40.f ? -40.f : (e > 40.f ? 40.f : e);
+  return std::exp2(e);
+}
+Bound ln_bound(const HostTensor* g, const HostTensor* b, float extra_each = 0.f) {
+  const size_t d = g->data.size();
+  float gm = 0.f, bm = 0.f;
+  double b2 = 0.0;
+  for (size_t i = 0; i < d; ++i) {
+    gm = std::fmax(gm, std::fabs(g->data[i]));
+    bm = std::fmax(bm, std::fabs(b->data[i]));
+    b2 += (double)b->data[i] * b->data[i];
+  }
+  const float sd = std::sqrt((float)d);
+  return Bound{gm * sd + bm + extra_each, gm * sd + (float)std::sqrt(b2) + extra_each * sd};
+}
+// bound of a dense layer's outputs (rows [r0, r1) of W [N][K]) for inputs with ||x||_2 <= in_l2
+float dense_bound(const float* W, const float* bias, int r0, int r1, int K, float in_l2) {
+  float worst = 0.f;
+  for (int j = r0; j < r1; ++j) {
+    double n2 = 0.0;
+    for (int k = 0; k < K; ++k) n2 += (double)W[(size_t)j * K + k] * W[(size_t)j * K + k];
+    worst = std::fmax(worst, (float)std::sqrt(n2) * in_l2 + std::fabs(bias[j]));
+  }
+  return worst;
 }
 
 // expected shape of a state_dict entry; returns false if the name is not a parameter we consume
@@ -230,52 +297,112 @@ const HostTensor* need(fd_model* m, const std::string& name) {
   return &it->second;
 }
 
+void drop_workspaces(fd_model* m) {
+  m->ws.release();
+  for (Workspace& w : m->cache) w.release();
+  m->cache.clear();
+}
+
 int ensure_ws(fd_model* m, int B, int L) {
   Workspace& w = m->ws;
-  if (w.B == B && w.L == L) return FD_OK;
-  HIP_TRY(hipStreamSynchronize(m->stream));
-  w.release();
   const fd_config& c = m->cfg;
   const size_t M = (size_t)B * L, d = c.d_model, F = c.n_features;
-  const size_t gmax = c.d_ff > c.d_model ? c.d_ff : c.d_model;
-  // Token-row buffers that feed or leave the LN-fused GEMMs are padded to whole 128-row tiles and
-  // zeroed once: the fused kernels then run on full tiles for any B*L (rows are independent; the
-  // padding rows stay finite and are never read back).
-  const size_t Mp = (M + 127) / 128 * 128;
+  // algorithmic work per launch (SURVEY 8a / 8d): 2*M*N*K for GEMMs, 6*L*d per token for attention
+  {
+    const double Md = (double)M, dd = (double)d, ff = (double)c.d_ff, Ld = (double)L;
+    double* fl = m->prof_flops;
+    double* by = m->prof_bytes;
+    const bool img = m->img;
+    fl[KC_EMBED] = 2 * Md * F * dd;            by[KC_EMBED] = 4 * (Md * F + Md * dd);
+    fl[KC_GEMM_QKV] = 2 * Md * (img ? 2 : 3) * dd * dd;
+    by[KC_GEMM_QKV] = 4 * (Md * dd + (img ? 2 : 3) * dd * dd + Md * (img ? 2 : 3) * dd);
+    fl[KC_GEMM_V] = 2 * Md * dd * dd;          by[KC_GEMM_V] = 4 * (2 * Md * dd + dd * dd);
+    fl[KC_ATTN] = 6 * Ld * dd * Md;            by[KC_ATTN] = 4 * (Md * 3 * dd + Md * dd);
+    fl[KC_GEMM_OUT] = 2 * Md * dd * dd;        by[KC_GEMM_OUT] = 4 * (3 * Md * dd + dd * dd);
+    fl[KC_LN1] = 0;                            by[KC_LN1] = 4 * 2 * Md * dd;
+    fl[KC_GEMM_UP] = 2 * Md * ff * dd;         by[KC_GEMM_UP] = 4 * (Md * dd + ff * dd + Md * ff);
+    fl[KC_GEMM_DOWN] = 2 * Md * ff * dd;       by[KC_GEMM_DOWN] = 4 * (Md * ff + ff * dd + 2 * Md * dd);
+    fl[KC_LN2] = 0;                            by[KC_LN2] = 4 * 2 * Md * dd;
+    fl[KC_GEMM_HEAD] = 2 * Md * dd * dd;       by[KC_GEMM_HEAD] = 4 * (2 * Md * dd + dd * dd);
+    fl[KC_HEAD_UPDATE] = 2 * Md * dd * F;      by[KC_HEAD_UPDATE] = 4 * (Md * dd + 3 * Md * F);
+    fl[KC_ADVANCE] = 0;                        by[KC_ADVANCE] = 4;
+  }
+  w.last_use = ++m->use_clock;
+  if (w.B == B && w.L == L) return FD_OK;
+  // park the current workspace and look for a cached one of this shape
+  if (w.B != 0) {
+    m->cache.push_back(w);
+    w = Workspace();
+  }
+  for (size_t i = 0; i < m->cache.size(); ++i)
+    if (m->cache[i].B == B && m->cache[i].L == L) {
+      w = m->cache[i];
+      m->cache.erase(m->cache.begin() + i);
+      w.last_use = m->use_clock;
+      return FD_OK;
+    }
+  while (m->cache.size() >= 3) {  // keep at most 4 shapes alive (C2-sized workspaces are about 1 GB each)
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    size_t old = 0;
+    for (size_t i = 1; i < m->cache.size(); ++i)
+      if (m->cache[i].last_use < m->cache[old].last_use) old = i;
+    m->cache[old].release();
+    m->cache.erase(m->cache.begin() + old);
+  }
   auto al = [&](void** p, size_t bytes) -> hipError_t { return hipMalloc(p, bytes); };
   auto alz = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(p, bytes);
     return e != hipSuccess ? e : hipMemsetAsync(*p, 0, bytes, m->stream);
   };
   HIP_TRY(al((void**)&w.x, M * F * 4));
-  HIP_TRY(al((void**)&w.eps, M * F * 4));
+  HIP_TRY(alz((void**)&w.eps, M * F * 4));
   HIP_TRY(al((void**)&w.z, M * F * 4));
-  HIP_TRY(alz((void**)&w.h, Mp * d * 4));
-  HIP_TRY(alz((void**)&w.qkv, Mp * 3 * d * 4));
-  HIP_TRY(alz((void**)&w.ctx, Mp * d * 4));
-  HIP_TRY(alz((void**)&w.a, Mp * d * 4));
-  HIP_TRY(al((void**)&w.tmp, M * d * 4));
-  HIP_TRY(alz((void**)&w.g, Mp * gmax * 4));
   HIP_TRY(al((void**)&w.lens, (size_t)B * 4));
-  HIP_TRY(al((void**)&w.t_dev, 16));
+  HIP_TRY(alz((void**)&w.t_dev, 16));
   HIP_TRY(al((void**)&w.dyn, sizeof(UpdateDyn)));
+  if (m->img) {
+    // Row images: sequences start at multiples of 8 rows, the row count is rounded up to whole 128-row tiles.
+    // Everything is zeroed once: padding rows / never-written key slots stay finite for ever.
+    const size_t Lr = (size_t)(L + 7) / 8 * 8;
+    const size_t cap = (B * Lr + 127) / 128 * 128;
+    const int T = L > 128 ? 4 : (L + 31) / 32;
+    w.LPK = 32 * T;
+    w.NKT = L > 128 ? (L + 127) / 128 : 1;
+    w.LTOT = w.NKT * w.LPK;
+    w.cap = (int)cap;
+    const size_t BH = (size_t)B * c.n_heads, gmax = c.d_ff > c.d_model ? c.d_ff : c.d_model;
+    HIP_TRY(alz((void**)&w.himg, cap * d * 4));
+    HIP_TRY(alz((void**)&w.aimg, cap * d * 4));
+    HIP_TRY(alz((void**)&w.cimg, cap * d * 4));
+    HIP_TRY(alz((void**)&w.gimg, cap * gmax * 4));
+    HIP_TRY(alz((void**)&w.qbuf, BH * w.LTOT * 128));
+    HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 144));
+    HIP_TRY(alz((void**)&w.vbuf, BH * w.NKT * 32 * (size_t)(4 * w.LPK + 8)));
+    HIP_TRY(alz((void**)&w.trash, 1024));
+    HIP_TRY(alz((void**)&w.rowinfo, cap * sizeof(int2)));
+    HIP_TRY(alz((void**)&w.seq_row0, ((size_t)B + 1) * 4));
+    HIP_TRY(alz((void**)&w.nrow, (size_t)B * 4));
+    HIP_TRY(alz((void**)&w.dims, 16));
+    HIP_TRY(alz((void**)&w.flag, 16));
+    w.img = true;
+  } else {
+    const size_t gmax = c.d_ff > c.d_model ? c.d_ff : c.d_model;
+    // Token-row buffers that feed or leave the LN-fused GEMMs are padded to whole 128-row tiles and
+    // zeroed once: the fused kernels then run on full tiles for any B*L (rows are independent; the
+    // padding rows stay finite and are never read back).
+    const size_t Mp = (M + 127) / 128 * 128;
+    HIP_TRY(alz((void**)&w.h, Mp * d * 4));
+    HIP_TRY(alz((void**)&w.qkv, Mp * 3 * d * 4));
+    HIP_TRY(alz((void**)&w.ctx, Mp * d * 4));
+    HIP_TRY(alz((void**)&w.a, Mp * d * 4));
+    HIP_TRY(al((void**)&w.tmp, M * d * 4));
+    HIP_TRY(alz((void**)&w.g, Mp * gmax * 4));
+  }
   w.B = B;
   w.L = L;
-  // algorithmic work per launch (SURVEY 8a / 8d): 2*M*N*K for GEMMs, 6*L*d per token for attention
-  const double Md = (double)M, dd = (double)d, ff = (double)c.d_ff, Ld = (double)L;
-  double* fl = m->prof_flops;
-  double* by = m->prof_bytes;
-  fl[KC_EMBED] = 2 * Md * F * dd;            by[KC_EMBED] = 4 * (Md * F + Md * dd);
-  fl[KC_GEMM_QKV] = 2 * Md * 3 * dd * dd;    by[KC_GEMM_QKV] = 4 * (Md * dd + 3 * dd * dd + Md * 3 * dd);
-  fl[KC_ATTN] = 6 * Ld * dd * Md;            by[KC_ATTN] = 4 * (Md * 3 * dd + Md * dd);
-  fl[KC_GEMM_OUT] = 2 * Md * dd * dd;        by[KC_GEMM_OUT] = 4 * (3 * Md * dd + dd * dd);
-  fl[KC_LN1] = 0;                            by[KC_LN1] = 4 * 2 * Md * dd;
-  fl[KC_GEMM_UP] = 2 * Md * ff * dd;         by[KC_GEMM_UP] = 4 * (Md * dd + ff * dd + Md * ff);
-  fl[KC_GEMM_DOWN] = 2 * Md * ff * dd;       by[KC_GEMM_DOWN] = 4 * (Md * ff + ff * dd + 2 * Md * dd);
-  fl[KC_LN2] = 0;                            by[KC_LN2] = 4 * 2 * Md * dd;
-  fl[KC_GEMM_HEAD] = 2 * Md * dd * dd;       by[KC_GEMM_HEAD] = 4 * (2 * Md * dd + dd * dd);
-  fl[KC_HEAD_UPDATE] = 2 * Md * dd * F;      by[KC_HEAD_UPDATE] = 4 * (Md * dd + 3 * Md * F);
-  fl[KC_ADVANCE] = 0;                        by[KC_ADVANCE] = 4;
+  w.last_use = m->use_clock;
+  // the zero fills ran on the model's stream; the caller may continue on another one
+  HIP_TRY(hipStreamSynchronize(m->stream));
   return FD_OK;
 }
 
@@ -347,7 +474,10 @@ void gemm(fd_model* m, int epi, const float* A, const float* W, const SplitW& Ws
   else launch_gemm_f32(epi, A, W, bias, resid, C, M, N, K, s);
 }
 
+int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode);
+
 int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
+  if (m->ws.img) return run_step_img(m, s, mode);
   const fd_config& c = m->cfg;
   Workspace& w = m->ws;
   const int B = w.B, L = w.L, M = B * L, d = c.d_model, ff = c.d_ff, F = c.n_features;
@@ -439,6 +569,139 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
   return FD_OK;
 }
 
+
+// The same step on the row-image kernels (FD_PREC_F16X3): 6 launches per layer (QK, V^T, attention, attn-out + LN,
+// FFN-up + GELU, FFN-down + LN), every activation an fp16 hi|lo image, no separate step-advance launch.
+int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
+  int launches = 0;
+#define DBG_STOP() do { if (m->debug_stop > 0 && ++launches >= m->debug_stop) { HIP_TRY(hipGetLastError()); return FD_OK; } } while (0)
+  const fd_config& c = m->cfg;
+  Workspace& w = m->ws;
+  const int B = w.B, L = w.L, d = c.d_model, ff = c.d_ff, F = c.n_features, H = c.n_heads;
+  const int max_rows = w.cap;
+  {
+    EmbedImgArgs e;
+    memset(&e, 0, sizeof e);
+    e.x = w.x; e.w_in = m->w_in; e.b_in = m->b_in; e.pos_emb = m->pos_emb; e.gamma = m->emb_g; e.beta = m->emb_b;
+    e.time_table = m->time_table; e.tslot = w.t_dev; e.rowinfo = w.rowinfo; e.nrow = w.nrow; e.dims = w.dims;
+    e.h = w.himg; e.L = L; e.F = F; e.d = d; e.eps = c.ln_eps; e.out_scale = m->layers[0].s_h;
+    PROF(KC_EMBED, launch_embed_img(e, max_rows, s));
+      DBG_STOP();
+  }
+  auto base = [&]() {
+    GemmImgArgs g;
+    memset(&g, 0, sizeof g);
+    g.trash = w.trash; g.rowinfo = w.rowinfo; g.dims = w.dims;
+    g.H = H; g.LPK = w.LPK; g.LTOT = w.LTOT; g.NKT = w.NKT;
+    g.eps = c.ln_eps;
+    return g;
+  };
+  for (int li = 0; li < c.n_layers; ++li) {
+    const LayerDev& lw = m->layers[li];
+    const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
+    {
+      GemmImgArgs g = base();
+      g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqk_i.p); g.bias = lw.bqk;
+      g.qbuf = w.qbuf; g.kbuf = w.kbuf; g.N = 2 * d; g.K = d;
+      g.acc_scale = 1.0f / (lw.s_h * lw.wqk_i.scale); g.q_scale = lw.s_q; g.k_scale = lw.s_k;
+      PROF(KC_GEMM_QKV, launch_gemm_img(EPI_IMG_QK, g, max_rows, s));
+      DBG_STOP();
+    }
+    {
+      GemmImgArgs g = base();
+      g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wv_i.p); g.bias = lw.bv;
+      g.vbuf = w.vbuf; g.N = d; g.K = d;
+      g.acc_scale = 1.0f / (lw.s_h * lw.wv_i.scale); g.v_scale = lw.s_v;
+      PROF(KC_GEMM_V, launch_gemm_img(EPI_IMG_VT, g, max_rows, s));
+      DBG_STOP();
+    }
+    {
+      AttnImgArgs a;
+      memset(&a, 0, sizeof a);
+      a.qbuf = w.qbuf; a.kbuf = w.kbuf; a.vbuf = w.vbuf;
+      a.demb = static_cast<const u32x4_t*>(lw.demb_s.p);
+      a.lens = w.lens; a.nrow = w.nrow; a.seq_row0 = w.seq_row0; a.ctx = w.cimg; a.trash = w.trash;
+      a.B = B; a.H = H; a.LTOT = w.LTOT; a.NKT = w.NKT; a.maxpos = c.max_pos;
+      a.q_scale = lw.s_q; a.k_scale = lw.s_k; a.v_scale = lw.s_v; a.ctx_scale = lw.s_v;
+      a.r_scale = lw.demb_s.p ? lw.s_k / lw.demb_s.scale : 1.f;
+      bool ok = true;
+      PROF(KC_ATTN, ok = launch_attention_img(a, L, s));
+      if (!ok) return fail(FD_E_UNSUPPORTED, "attention: L=%d", L);
+      DBG_STOP();
+    }
+    {
+      GemmImgArgs g = base();
+      g.A = w.cimg; g.W = static_cast<const unsigned char*>(lw.wo_i.p); g.bias = lw.bo; g.gamma = lw.ln1g; g.beta = lw.ln1b;
+      g.resid = w.himg; g.out = w.aimg; g.N = d; g.K = d;
+      g.acc_scale = 1.0f / (lw.s_v * lw.wo_i.scale); g.resid_inv = 1.0f / lw.s_h; g.out_scale = lw.s_a;
+      PROF(KC_GEMM_OUT, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
+      DBG_STOP();
+    }
+    {
+      GemmImgArgs g = base();
+      g.A = w.aimg; g.W = static_cast<const unsigned char*>(lw.wi_i.p); g.bias = lw.bi; g.out = w.gimg; g.N = ff; g.K = d;
+      g.acc_scale = 1.0f / (lw.s_a * lw.wi_i.scale); g.out_scale = lw.s_g;
+      PROF(KC_GEMM_UP, launch_gemm_img(EPI_IMG_GELU, g, max_rows, s));
+      DBG_STOP();
+    }
+    {
+      GemmImgArgs g = base();
+      g.A = w.gimg; g.W = static_cast<const unsigned char*>(lw.wd_i.p); g.bias = lw.bd; g.gamma = lw.ln2g; g.beta = lw.ln2b;
+      g.resid = w.aimg; g.out = w.himg; g.N = d; g.K = ff;
+      g.acc_scale = 1.0f / (lw.s_g * lw.wd_i.scale); g.resid_inv = 1.0f / lw.s_a; g.out_scale = s_next;
+      PROF(KC_GEMM_DOWN, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
+      DBG_STOP();
+    }
+  }
+  UpdateArgs u;
+  memset(&u, 0, sizeof u);
+  HeadImgArgs hi;
+  memset(&hi, 0, sizeof hi);
+  if (c.decoder == FD_DEC_MLP) {
+    GemmImgArgs g = base();
+    g.A = w.himg; g.W = static_cast<const unsigned char*>(m->hd_w1_i.p); g.bias = m->hd_b1; g.out = w.gimg; g.N = d; g.K = d;
+    g.acc_scale = 1.0f / (m->s_hfinal * m->hd_w1_i.scale); g.out_scale = m->s_hg;
+    PROF(KC_GEMM_HEAD, launch_gemm_img(EPI_IMG_GELU, g, max_rows, s));
+      DBG_STOP();
+    hi.g = w.gimg; hi.g_inv = 1.0f / m->s_hg;
+    u.gamma = m->hd_g; u.beta = m->hd_b; u.do_ln = 1;
+  } else {
+    hi.g = w.himg; hi.g_inv = 1.0f / m->s_hfinal;
+    u.do_ln = 0;
+  }
+  hi.rowinfo = w.rowinfo; hi.nrow = w.nrow; hi.dims = w.dims; hi.tslot = w.t_dev; hi.flag = w.flag;
+  hi.advance = mode.advance ? 1 : 0;
+  u.w2 = m->hd_w2; u.b2 = m->hd_b2; u.x = w.x; u.coef = m->coef; u.t_dev = w.t_dev; u.T = m->T;
+  u.M = B * L; u.L = L; u.F = F; u.d = d;
+  u.ln_eps = 1e-12f;  // AnglesPredictor(eps=1e-12)  (modelling.py:187,199)
+  u.angle_mask = mode.no_wrap ? 0u : m->angle_mask;
+  u.eps_out = w.eps;
+  if (!mode.forward_only) {
+    u.x_out = w.x;
+    if (mode.use_dyn) {
+      u.dyn = w.dyn;
+    } else {
+      u.noise = mode.noise;
+      u.noise_stride = 0;
+      u.t_start = mode.t_start;
+    }
+  }
+  if (mode.use_dyn) u.noise_stride = (long long)B * L * F;
+  PROF(KC_HEAD_UPDATE, launch_head_update_img(u, hi, max_rows, s));
+  HIP_TRY(hipGetLastError());
+  return FD_OK;
+#undef DBG_STOP
+}
+
+// token-row table of the batch (row-image path); `packed`: only the first lens[b] positions are rows
+int prepare_rows(fd_model* m, hipStream_t s, int packed) {
+  Workspace& w = m->ws;
+  if (!w.img) return FD_OK;
+  launch_build_rows(w.lens, w.B, w.L, packed, w.cap, w.seq_row0, w.nrow, w.rowinfo, w.dims, s);
+  HIP_TRY(hipGetLastError());
+  return FD_OK;
+}
+
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void set_dyn_kernel(UpdateDyn* p, UpdateDyn v) { *p = v; }
 
@@ -499,6 +762,113 @@ int ensure_graph(fd_model* m) {
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess) return fail(FD_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   w.graph_fuse_ln = m->fuse_ln;
+  return FD_OK;
+}
+
+// SURVEY 5 (failure detection): the update kernel raises a device flag when the model output is not finite
+// (it would silently poison every later step).  Call with the model's work complete.
+int check_flag(fd_model* m) {
+  Workspace& w = m->ws;
+  if (!w.img || !w.flag) return FD_OK;
+  int v = 0;
+  HIP_TRY(hipMemcpy(&v, w.flag, 4, hipMemcpyDeviceToHost));
+  if (!v) return FD_OK;
+  HIP_TRY(hipMemset(w.flag, 0, 4));
+  return fail(FD_E_NONFINITE, "the model produced a non-finite value (inf/NaN in the predicted noise)");
+}
+
+// Test hook plumbing of the row-image GEMM: fp32 host operands -> images (scales chosen from the data exactly as
+// fd_finalize chooses them from weight bounds) -> production kernel -> fp32.
+struct ImgHook {
+  std::vector<void*> bufs;
+  ~ImgHook() {
+    for (void* p : bufs) (void)hipFree(p);
+  }
+  hipError_t up(const void* host, size_t bytes, void** dev) {
+    hipError_t e = hipMalloc(dev, bytes);
+    if (e != hipSuccess) return e;
+    bufs.push_back(*dev);
+    return host ? hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice) : hipMemset(*dev, 0, bytes);
+  }
+};
+
+float max_abs(const float* p, size_t n) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p[i]));
+  return mx;
+}
+
+// epilogue: EPI_IMG_BIAS | EPI_IMG_GELU | EPI_IMG_LN
+int img_gemm_hook(int epilogue, const float* A, const float* W, const float* bias, const float* resid, const float* gamma,
+                  const float* beta, float eps, float* C, int M, int N, int K) {
+  if (N % 32 || K % 32) return fail(FD_E_UNSUPPORTED, "row-image GEMM: N=%d and K=%d must be multiples of 32", N, K);
+  if (epilogue == EPI_IMG_LN && N > 384) return fail(FD_E_UNSUPPORTED, "LN-fused GEMM: N=%d > 384", N);
+  ImgHook hk;
+#define I_TRY(expr)                                                                               \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+  } while (0)
+  const long long rows = ((long long)M + 127) / 128 * 128;
+  float *dA, *db, *dg = nullptr, *dbt = nullptr, *dR = nullptr, *dC;
+  void *dAi, *dWi, *dRi = nullptr, *dOi, *dtrash;
+  int* ddims;
+  I_TRY(hk.up(A, (size_t)M * K * 4, (void**)&dA));
+  I_TRY(hk.up(bias, (size_t)N * 4, (void**)&db));
+  I_TRY(hk.up(nullptr, (size_t)rows * K * 4, &dAi));
+  I_TRY(hk.up(nullptr, (size_t)rows * N * 4, &dOi));
+  I_TRY(hk.up(nullptr, (size_t)rows * N * 4, (void**)&dC));
+  I_TRY(hk.up(nullptr, 1024, &dtrash));
+  const int hd[2] = {M, (int)rows};
+  I_TRY(hk.up(hd, sizeof hd, (void**)&ddims));
+  std::vector<uint16_t> img;
+  float wscale = 1.f;
+  pack_split_weight(W, N, K, &img, &wscale, 384);
+  I_TRY(hk.up(img.data(), img.size() * 2, &dWi));
+  const float a_scale = scale_for(max_abs(A, (size_t)M * K));
+  launch_f32_to_img(dA, dAi, rows, K, M, a_scale, nullptr);
+  // output bound as fd_finalize derives it: ||row of A||_2 ||row of W||_2 + |bias| (+ residual); LayerNorm: gamma/beta
+  float in_l2 = 0.f;
+  for (int r = 0; r < M; ++r) {
+    double n2 = 0.0;
+    for (int k = 0; k < K; ++k) n2 += (double)A[(size_t)r * K + k] * A[(size_t)r * K + k];
+    in_l2 = std::fmax(in_l2, (float)std::sqrt(n2));
+  }
+  GemmImgArgs g;
+  memset(&g, 0, sizeof g);
+  g.A = static_cast<const unsigned char*>(dAi);
+  g.W = static_cast<const unsigned char*>(dWi);
+  g.bias = db;
+  g.out = static_cast<unsigned char*>(dOi);
+  g.trash = static_cast<unsigned char*>(dtrash);
+  g.dims = ddims;
+  g.N = N;
+  g.K = K;
+  g.acc_scale = 1.0f / (a_scale * wscale);
+  g.eps = eps;
+  float out_scale;
+  if (epilogue == EPI_IMG_LN) {
+    I_TRY(hk.up(gamma, (size_t)N * 4, (void**)&dg));
+    I_TRY(hk.up(beta, (size_t)N * 4, (void**)&dbt));
+    I_TRY(hk.up(resid, (size_t)M * N * 4, (void**)&dR));
+    I_TRY(hk.up(nullptr, (size_t)rows * N * 4, &dRi));
+    const float r_scale = scale_for(max_abs(resid, (size_t)M * N));
+    launch_f32_to_img(dR, dRi, rows, N, M, r_scale, nullptr);
+    g.resid = static_cast<const unsigned char*>(dRi);
+    g.resid_inv = 1.0f / r_scale;
+    g.gamma = dg;
+    g.beta = dbt;
+    out_scale = scale_for(max_abs(gamma, N) * std::sqrt((float)N) + max_abs(beta, N));
+  } else {
+    out_scale = scale_for(dense_bound(W, bias, 0, N, K, in_l2));
+  }
+  g.out_scale = out_scale;
+  launch_gemm_img(epilogue, g, (int)rows, nullptr);
+  launch_img_to_f32(dOi, dC, rows, N, out_scale, nullptr);
+  I_TRY(hipGetLastError());
+  I_TRY(hipDeviceSynchronize());
+  I_TRY(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+#undef I_TRY
   return FD_OK;
 }
 
@@ -575,10 +945,14 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
   if (precision != FD_PREC_F32 && precision != FD_PREC_F16X3) return fail(FD_E_UNSUPPORTED, "precision mode %d", precision);
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
-  m->ws.release();
+  drop_workspaces(m);
   free_weights(m);
   const fd_config& c = m->cfg;
   const size_t d = c.d_model, F = c.n_features, ff = c.d_ff;
+  // FD_PREC_F16X3 runs on the row-image kernels (LayerNorm rows must fit one 384-column workgroup tile);
+  // FDMI_IMG=0 keeps the previous register-staged split kernels (A/B knob)
+  const bool img = precision == FD_PREC_F16X3 && d <= 384 && img_path_enabled();
+  m->img = img;
 #define NEED(var, nm)                         \
   const HostTensor* var = need(m, nm);        \
   if (!var) return FD_E_MISSING
@@ -592,6 +966,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
   UP(m->b_in, t_bin);
   UP(m->emb_g, t_eg);
   UP(m->emb_b, t_eb);
+  // bound of the hidden state entering layer 0: embeddings LayerNorm + time embedding (|sin|, |cos| <= 1)
+  Bound hb = ln_bound(t_eg, t_eb, 1.0f);
   m->pos_emb = nullptr;
   if (c.pos_type == FD_POS_ABSOLUTE) {
     NEED(t_pe, "embeddings.position_embeddings.weight");
@@ -613,8 +989,18 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     for (const HostTensor* t : {bq, bk, bv}) bqkv.insert(bqkv.end(), t->data.begin(), t->data.end());
     if (int rc = upload(m, &lw.wqkv, wqkv.data(), wqkv.size())) return rc;
     if (int rc = upload(m, &lw.bqkv, bqkv.data(), bqkv.size())) return rc;
-    if (precision == FD_PREC_F16X3)
+    if (precision == FD_PREC_F16X3 && !img)
       if (int rc = upload_split(m, &lw.wqkv_s, wqkv.data(), 3 * (int)d, (int)d)) return rc;
+    if (img) {
+      if (int rc = upload_split(m, &lw.wqk_i, wqkv.data(), 2 * (int)d, (int)d, 384)) return rc;
+      if (int rc = upload_split(m, &lw.wv_i, wqkv.data() + 2 * d * d, (int)d, (int)d, 384)) return rc;
+      lw.bqk = lw.bqkv;
+      lw.bv = lw.bqkv + 2 * d;
+      lw.s_h = scale_for(hb.linf);
+      lw.s_q = scale_for(dense_bound(wqkv.data(), bqkv.data(), 0, (int)d, (int)d, hb.l2));
+      lw.s_k = scale_for(dense_bound(wqkv.data(), bqkv.data(), (int)d, 2 * (int)d, (int)d, hb.l2));
+      lw.s_v = scale_for(dense_bound(wqkv.data(), bqkv.data(), 2 * (int)d, 3 * (int)d, (int)d, hb.l2));  // also bounds ctx
+    }
     lw.demb = nullptr;
     if (c.pos_type == FD_POS_RELATIVE_KEY) {
       NEED(de, p + "attention.self.distance_embedding.weight");
@@ -634,12 +1020,22 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     NEED(b2, p + "output.LayerNorm.bias");
     UP(lw.wo, wo); UP(lw.bo, bo); UP(lw.ln1g, g1); UP(lw.ln1b, b1);
     UP(lw.wi, wi); UP(lw.bi, bi); UP(lw.wd, wd); UP(lw.bd, bd); UP(lw.ln2g, g2); UP(lw.ln2b, b2);
-    if (precision == FD_PREC_F16X3) {
+    if (precision == FD_PREC_F16X3 && !img) {
       if (int rc = upload_split(m, &lw.wo_s, wo->data.data(), (int)d, (int)d)) return rc;
       if (int rc = upload_split(m, &lw.wi_s, wi->data.data(), (int)ff, (int)d)) return rc;
       if (int rc = upload_split(m, &lw.wd_s, wd->data.data(), (int)d, (int)ff)) return rc;
     }
+    if (img) {
+      if (int rc = upload_split(m, &lw.wo_i, wo->data.data(), (int)d, (int)d, 384)) return rc;
+      if (int rc = upload_split(m, &lw.wi_i, wi->data.data(), (int)ff, (int)d, 384)) return rc;
+      if (int rc = upload_split(m, &lw.wd_i, wd->data.data(), (int)d, (int)ff, 384)) return rc;
+      const Bound ab = ln_bound(g1, b1);
+      lw.s_a = scale_for(ab.linf);
+      lw.s_g = scale_for(dense_bound(wi->data.data(), bi->data.data(), 0, (int)ff, (int)d, ab.l2));  // |gelu(u)| <= |u|
+      hb = ln_bound(g2, b2);  // hidden state entering the next layer
+    }
   }
+  m->s_hfinal = scale_for(hb.linf);
   if (c.decoder == FD_DEC_MLP) {
     NEED(w1, "token_decoder.dense1.weight");
     NEED(b1, "token_decoder.dense1.bias");
@@ -648,8 +1044,12 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     NEED(w2, "token_decoder.dense2.weight");
     NEED(b2, "token_decoder.dense2.bias");
     UP(m->hd_w1, w1); UP(m->hd_b1, b1); UP(m->hd_g, g); UP(m->hd_b, b); UP(m->hd_w2, w2); UP(m->hd_b2, b2);
-    if (precision == FD_PREC_F16X3)
+    if (precision == FD_PREC_F16X3 && !img)
       if (int rc = upload_split(m, &m->hd_w1_s, w1->data.data(), (int)d, (int)d)) return rc;
+    if (img) {
+      if (int rc = upload_split(m, &m->hd_w1_i, w1->data.data(), (int)d, (int)d, 384)) return rc;
+      m->s_hg = scale_for(dense_bound(w1->data.data(), b1->data.data(), 0, (int)d, (int)d, hb.l2));
+    }
   } else {
     NEED(w2, "token_decoder.weight");
     NEED(b2, "token_decoder.bias");
@@ -672,7 +1072,7 @@ void fd_destroy(fd_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  m->ws.release();
+  drop_workspaces(m);
   free_weights(m);
   for (PendingEvent& p : m->pending) {
     (void)hipEventDestroy(p.e0);
@@ -688,6 +1088,9 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   const std::string n = name;
   if (n == "fuse_ln") m->fuse_ln = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
+  else if (n == "varlen") m->varlen = value ? 1 : 0;
+  else if (n == "debug_stop") m->debug_stop = value;
+  else if (n == "debug_layer") m->debug_layer = value;
   else if (n == "attn_f16") {
     m->attn_f16 = value ? 1 : 0;
     m->ws.graph_fuse_ln = -2;  // force a re-capture
@@ -707,13 +1110,14 @@ int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, i
   hipStream_t s = m->stream;
   HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(w.lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  if (int rc = prepare_rows(m, s, 0)) return rc;  // the forward defines every position, masked ones included
   if (int rc = set_t(m, s, t)) return rc;
   StepMode mode{};
   mode.forward_only = true;
   if (int rc = run_step(m, s, mode)) return rc;
   HIP_TRY(hipMemcpyAsync(eps_out, w.eps, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  return FD_OK;
+  return check_flag(m);
 }
 
 int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, const float* z, int wrap,
@@ -730,6 +1134,7 @@ int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, in
   HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(w.lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
   if (z) HIP_TRY(hipMemcpyAsync(w.z, z, n * 4, hipMemcpyHostToDevice, s));
+  if (int rc = prepare_rows(m, s, 0)) return rc;
   if (int rc = set_t(m, s, t)) return rc;
   StepMode mode{};
   mode.noise = w.z;
@@ -738,7 +1143,7 @@ int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, in
   if (int rc = run_step(m, s, mode)) return rc;
   HIP_TRY(hipMemcpyAsync(x_out, w.x, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  return FD_OK;
+  return check_flag(m);
 }
 
 int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
@@ -749,13 +1154,19 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
   if (full_history < 0) return fail(FD_E_INVALID, "full_history = %d", full_history);
   HIP_TRY(hipSetDevice(m->device));
   if (int rc = ensure_ws(m, B, L)) return rc;
-  if (m->use_graph)
-    if (int rc = ensure_graph(m)) return rc;
   Workspace& w = m->ws;
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
   const size_t n = (size_t)B * L * m->cfg.n_features;
   HIP_TRY(hipMemcpyAsync(w.x, x_init_dev, n * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(w.lens, lens_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  if (int rc = prepare_rows(m, s, m->varlen)) return rc;
+  if (m->use_graph && !(w.graph && w.graph_fuse_ln == m->fuse_ln)) {
+    // first use of this (B, L): the warm-up step and the capture run on the model's stream and need the
+    // lengths / row table that were just queued on `s`
+    if (s != m->stream) HIP_TRY(hipStreamSynchronize(s));
+    if (int rc = ensure_graph(m)) return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+  }
   UpdateDyn dyn;
   memset(&dyn, 0, sizeof dyn);
   dyn.noise = static_cast<const float*>(noise_dev);
@@ -827,7 +1238,7 @@ int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int 
   TRY_CLEAN(hipMemcpy(out, d_out, out_rows * n * 4, hipMemcpyDeviceToHost));
 #undef TRY_CLEAN
   cleanup();
-  return FD_OK;
+  return check_flag(m);
 }
 
 int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, int B, int L, void* out_dev,
@@ -884,6 +1295,11 @@ int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, con
   if (epilogue < EPI_BIAS || epilogue > EPI_BIAS_RESID || (epilogue == EPI_BIAS_RESID && !resid))
     return fail(FD_E_INVALID, "bad epilogue");
   HIP_TRY(hipSetDevice(device_id));
+  if (precision == FD_PREC_F16X3 && img_path_enabled()) {
+    if (epilogue == EPI_BIAS_RESID)
+      return fail(FD_E_UNSUPPORTED, "the row-image path has no unfused residual epilogue (LayerNorm is always fused): use fd_test_gemm_ln");
+    return img_gemm_hook(epilogue == EPI_BIAS_GELU ? EPI_IMG_GELU : EPI_IMG_BIAS, A, W, bias, nullptr, nullptr, nullptr, 0.f, C, M, N, K);
+  }
   float *dA = nullptr, *dW = nullptr, *db = nullptr, *dr = nullptr, *dC = nullptr;
   void* dWp = nullptr;
   float wscale = 1.f;
@@ -938,6 +1354,10 @@ int fd_test_gemm_ln(int device_id, int precision, int use_fused, const float* A,
     return fail(FD_E_INVALID, "bad argument");
   if (precision != FD_PREC_F32 && precision != FD_PREC_F16X3) return fail(FD_E_INVALID, "precision %d", precision);
   HIP_TRY(hipSetDevice(device_id));
+  if (precision == FD_PREC_F16X3 && img_path_enabled()) {
+    if (!use_fused) return fail(FD_E_UNSUPPORTED, "the row-image path always fuses the LayerNorm into the GEMM");
+    return img_gemm_hook(EPI_IMG_LN, A, W, bias, resid, gamma, beta, eps, C, M, N, K);
+  }
   std::vector<void*> bufs;
   auto cleanup = [&]() {
     for (void* p : bufs) (void)hipFree(p);
@@ -1087,6 +1507,66 @@ int fd_synchronize(fd_model* m) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return FD_OK;
+}
+
+int fd_debug_read(fd_model* m, const char* name, float* out, int64_t n_floats) {
+  if (!m || !name || !out) return fail(FD_E_INVALID, "null argument");
+  Workspace& w = m->ws;
+  if (!w.img) return fail(FD_E_STATE, "fd_debug_read: the current workspace is not on the row-image path");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  const fd_config& c = m->cfg;
+  const std::string nm = name;
+  const int li = m->debug_layer < c.n_layers ? m->debug_layer : c.n_layers - 1;
+  const LayerDev& lw = m->layers[li];
+  const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
+  const long long BH = (long long)w.B * c.n_heads;
+  long long need = 0;
+  float* tmp = nullptr;
+  auto img = [&](const unsigned char* src, int K, float scale) -> int {
+    need = (long long)w.cap * K;
+    if (n_floats < need) return fail(FD_E_INVALID, "fd_debug_read(%s): need %lld floats", name, need);
+    HIP_TRY(hipMalloc((void**)&tmp, need * 4));
+    launch_img_to_f32(src, tmp, w.cap, K, scale, m->stream);
+    return FD_OK;
+  };
+  auto qkv = [&](const unsigned char* src, int rowbytes, int is_vt, float scale) -> int {
+    need = BH * w.LTOT * 32;
+    if (n_floats < need) return fail(FD_E_INVALID, "fd_debug_read(%s): need %lld floats", name, need);
+    HIP_TRY(hipMalloc((void**)&tmp, need * 4));
+    launch_qkv_unpack(src, tmp, BH, w.LTOT, w.LPK, rowbytes, is_vt, scale, m->stream);
+    return FD_OK;
+  };
+  int rc;
+  if (nm == "h") rc = img(w.himg, c.d_model, lw.s_h);            // input of layer debug_layer
+  else if (nm == "h_out") rc = img(w.himg, c.d_model, s_next);   // output of layer debug_layer
+  else if (nm == "a") rc = img(w.aimg, c.d_model, lw.s_a);
+  else if (nm == "ctx") rc = img(w.cimg, c.d_model, lw.s_v);
+  else if (nm == "g") rc = img(w.gimg, c.d_ff, lw.s_g);
+  else if (nm == "g_head") rc = img(w.gimg, c.d_model, m->s_hg);
+  else if (nm == "q") rc = qkv(w.qbuf, 128, 0, lw.s_q);
+  else if (nm == "k") rc = qkv(w.kbuf, 144, 0, lw.s_k);
+  else if (nm == "v") rc = qkv(w.vbuf, 0, 1, lw.s_v);
+  else if (nm == "rowinfo") {
+    need = 2LL * w.cap;
+    if (n_floats < need) return fail(FD_E_INVALID, "fd_debug_read(rowinfo): need %lld", need);
+    std::vector<int> t(need);
+    HIP_TRY(hipMemcpy(t.data(), w.rowinfo, need * 4, hipMemcpyDeviceToHost));
+    for (long long i = 0; i < need; ++i) out[i] = (float)t[i];
+    return FD_OK;
+  } else return fail(FD_E_INVALID, "fd_debug_read: unknown buffer '%s'", name);
+  if (rc) return rc;
+  hipError_t e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, tmp, need * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(FD_E_HIP, "fd_debug_read: %s", hipGetErrorString(e));
+  return FD_OK;
+}
+
+int fd_check_finite(fd_model* m) {
+  if (!m) return fail(FD_E_INVALID, "null model");
+  HIP_TRY(hipSetDevice(m->device));
+  return check_flag(m);
 }
 
 }  // extern "C"

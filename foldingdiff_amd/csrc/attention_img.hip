@@ -1,0 +1,382 @@
+// Multi-head self-attention on row images (HF BertSelfAttention 4.11.3 semantics incl. relative_key and the
+// additive -10000 key mask; math and citations in attention_f32.hip), three contractions as fp16 hi/lo split
+// triples on v_mfma_f32_32x32x16_f16 (fp32-class accuracy, see gemm_img.hip).
+//
+// Inputs are what the QK / V^T GEMM epilogues wrote, already split and already in the LDS layout:
+//     q   [b][h][LTOT rows][128 B]   hi d0-31 | lo d0-31
+//     k   [b][h][LTOT rows][144 B]   hi | lo | 16 B pad      (conflict-free 16-byte operand fetches)
+//     vt  [b][h][key tile][32 d][4 LP + 8 B]   hi keys | lo keys | pad   (V transposed; conflict-free 8-byte fetches)
+// so filling LDS is a linear LDS-DMA copy: no VGPR round trip, no split arithmetic, no ds_write.
+//
+// A 4-wave workgroup is persistent over (sequence, head, query group) items and treats the (item, key tile)
+// pairs as one stream with split-phase prefetch (one K buffer, one V buffer):
+//     [A] K(p), Q(p) landed | S^T = K Q^T and the relative-key band  | [B] K region free -> DMA K(p+1), Q(p+1)
+//         softmax                                                    | [C] V(p) landed
+//         O^T += V^T P^T                                             | [D] V region free -> DMA V(p+1)
+// so every copy has a whole compute phase to land.  Waits are counted (s_waitcnt vmcnt(N)), never 0 in the loop.
+// A wave owns one 32-query row block; S^T (keys x queries) puts a query's scores in one lane pair, so softmax is
+// in-register and P is already the B operand of the PV MFMA; the relative_key term is dense 32x32 tiles
+// R = Q E^T over the band, skewed through a per-wave LDS scratch (see the comments inside).
+// ctx leaves as a row image [token row][head h block] for the attention-output GEMM.
+#include <cstdlib>
+
+#include "fdmi_kernels.h"
+#include "img_common.h"
+
+namespace fdmi {
+namespace ai {
+
+constexpr int KROW = 144;
+constexpr int RLD = 36;
+constexpr float PS = 1024.0f;  // probabilities are <= 1
+constexpr float kLog2e = 1.44269504088896341f;
+constexpr float kInvSqrtD = 0.17677669529663687f;  // 1 / sqrt(32)
+
+__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+template <int T>
+struct Geo {
+  static constexpr int LP = 32 * T;
+  static constexpr int VROW = 4 * LP + 8;
+  static constexpr int Q_BYTES = LP * 128, K_BYTES = LP * KROW, V_BYTES = 32 * VROW;
+  static constexpr int QC = ceil_div(Q_BYTES, 1024), KC = ceil_div(K_BYTES, 1024), VC = ceil_div(V_BYTES, 1024);
+  static constexpr int QW = ceil_div(QC, 4), KW = ceil_div(KC, 4), VW = ceil_div(VC, 4);  // DMA pieces per wave
+  static constexpr int OFF_Q = 0, OFF_K = OFF_Q + QW * 4 * 1024, OFF_V = OFF_K + KW * 4 * 1024,
+                       OFF_R = OFF_V + VW * 4 * 1024;
+  static constexpr int SMEM_REL = OFF_R + 4 * 32 * RLD * 4, SMEM_ABS = OFF_R;
+};
+
+// SAFE: every wait is vmcnt(0) (debug aid for the counted-wait bookkeeping)
+template <int T, bool REL, bool SAFE>
+__global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
+  using G = Geo<T>;
+  constexpr int LP = G::LP, VROW = G::VROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem + G::OFF_Q;
+  unsigned char* Ks = smem + G::OFF_K;
+  unsigned char* Vt = smem + G::OFF_V;
+  float* Rs = reinterpret_cast<float*>(smem + G::OFF_R);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int H = p.H, nqg = p.NKT;  // query groups == key tiles
+  const int nitems = p.B * H * nqg;
+  float* Rw = Rs + wq * 32 * RLD;
+
+  // ---- the stream of (item, key tile) positions of this workgroup
+  struct Pos { int item, kt, b, h, qg, len, nkt; };
+  auto load_item = [&](Pos& s, int item) {
+    s.item = item;
+    s.kt = 0;
+    const int it = item < nitems ? item : nitems - 1;
+    s.qg = it % nqg;
+    s.h = (it / nqg) % H;
+    s.b = it / (nqg * H);
+    s.len = p.lens[s.b];
+    s.nkt = (s.len + LP - 1) / LP;  // key tiles holding at least one unmasked key (the rest contribute exactly 0)
+  };
+  auto advance = [&](Pos& s) {  // next position; past the end it stays on the last one (copies are repeated, harmlessly)
+    if (s.kt + 1 < s.nkt) { ++s.kt; return; }
+    if (s.item + (int)gridDim.x < nitems) load_item(s, s.item + gridDim.x);
+  };
+  auto is_last = [&](const Pos& s) { return s.kt + 1 >= s.nkt && s.item + (int)gridDim.x >= nitems; };
+
+  // linear LDS-DMA copies; wave w takes pieces w, w + 4, ...; indices past the end repeat the last piece
+  auto copy = [&](const unsigned char* src, int bytes, int npieces, int per_wave, unsigned char* dst_base) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < per_wave; ++i) {
+      int piece = wq + 4 * i;
+      piece = piece < npieces ? piece : npieces - 1;
+      dma16(rs, (lds_ptr_t)(dst_base) + piece * 1024, lane * 16, piece * 1024);
+    }
+  };
+  auto issue_kq = [&](const Pos& s, bool with_q) {
+    const size_t bh = (size_t)s.b * H + s.h;
+    copy(p.kbuf + (bh * p.LTOT + (size_t)s.kt * LP) * KROW, G::K_BYTES, G::KC, G::KW, Ks);
+    if (with_q) copy(p.qbuf + (bh * p.LTOT + (size_t)s.qg * LP) * 128, G::Q_BYTES, G::QC, G::QW, Qs);
+  };
+  auto issue_v = [&](const Pos& s) {
+    const size_t bh = (size_t)s.b * H + s.h;
+    copy(p.vbuf + ((bh * p.NKT + s.kt) * 32) * (size_t)VROW, G::V_BYTES, G::VC, G::VW, Vt);
+  };
+
+  if ((int)blockIdx.x >= nitems) return;
+  Pos cur, nxt;
+  load_item(cur, blockIdx.x);
+  issue_kq(cur, true);
+  issue_v(cur);
+  nxt = cur;
+  bool done = is_last(cur);
+  advance(nxt);
+
+  const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
+  const float mask_raw = -10000.0f * kLog2e / s_scale;                  // (1 - mask) * -10000 at the raw scale
+  f16x8 qh[2], ql[2];
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc;
+  bool stored_prev = false;  // the previous position ended an item (4 ctx stores are younger than its V copy)
+
+  for (;;) {
+    const int b = cur.b, h = cur.h, qg = cur.qg, kt = cur.kt, len = cur.len;
+    const int row0 = p.seq_row0[b];
+    const int nrows = p.seq_row0[b + 1] - row0;  // token rows of the sequence (multiple of 8, >= real rows)
+    const int Lb = p.nrow[b];                    // real rows: positions >= Lb are not keys at all
+    const int l0 = qg * LP + 32 * wq;
+    const bool active = wq < T && l0 < nrows;
+    const int r0 = kt * LP;
+    const bool first_tile = kt == 0;
+    const bool nxt_first = nxt.kt == 0 && !done;  // does the next position start an item (its Q travels with its K)
+
+    // ---- [A] K(p) (+ Q(p)) landed.  Younger: V(p) pieces, and the ctx stores of the previous position.
+    if (SAFE) FD_WAIT_VM(0);
+    else if (stored_prev) FD_WAIT_VM(G::VW + 4);
+    else FD_WAIT_VM(G::VW);
+    barrier_keep_vm();
+    if (first_tile) {
+      const unsigned char* qrow = Qs + (size_t)(32 * (wq < T ? wq : 0) + l31) * 128;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        qh[c] = *reinterpret_cast<const f16x8*>(qrow + 32 * c + 16 * half);
+        ql[c] = *reinterpret_cast<const f16x8*>(qrow + 64 + 32 * c + 16 * half);
+      }
+      m_run = -INFINITY;
+      l_run = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    }
+
+    f32x16 sacc[T];
+    if (active) {
+      // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+        const unsigned char* row = Ks + (size_t)(32 * t + l31) * KROW;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const f16x8 kh = *reinterpret_cast<const f16x8*>(row + 32 * c + 16 * half);
+          const f16x8 kl = *reinterpret_cast<const f16x8*>(row + 64 + 32 * c + 16 * half);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+        }
+      }
+      if constexpr (REL) {
+        // R tile q: rows = queries rowmap(r, half), cols = band index 32 q + l31 (band origin: this wave's row
+        // block).  S^T tile t element (key kl, query ql) needs band column j = ql - kl + 31 of the tile pair
+        // (q = T-1-t, q+1): j < 32 -> tile q, else tile q+1 column j-32.  Band row of R tile q, column l31:
+        //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + 32 q + l31, clamped: rows outside the table are only
+        // ever paired with padding keys / queries (L <= maxpos).
+        const float r_ratio = p.r_scale;  // k_scale / table scale: band sums -> the raw scale of the scores
+#pragma unroll
+        for (int qq = 0; qq <= T; ++qq) {
+          int m = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * qq;
+          m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
+          const u32x4_t* erow = p.demb + (size_t)m * 8;  // 128-byte image: units 0-3 hi d0-31, 4-7 lo
+          const u32x4 e0 = erow[half], e1 = erow[2 + half], e2 = erow[4 + half], e3 = erow[6 + half];
+          f32x16 racc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+          {
+            const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
+            const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], eh0, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], el0, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[0], eh0, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], eh1, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], el1, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[1], eh1, racc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // scratch row = query l31 (this lane); band column j = l31 - kl + 31 of the tile PAIR lives in tile q for
+          // j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise: both read scratch column j & 31
+          float gth[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            gth[r] = Rw[l31 * RLD + ((l31 - kl + 31) & 31)];
+          }
+          if (qq < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              sacc[T - 1 - qq][r] = __builtin_fmaf((l31 <= kl) ? gth[r] : 0.f, r_ratio, sacc[T - 1 - qq][r]);
+            }
+          }
+          if (qq > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              sacc[T - qq][r] = __builtin_fmaf((l31 > kl) ? gth[r] : 0.f, r_ratio, sacc[T - qq][r]);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next band tile overwrites this scratch
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+
+    // ---- [B] every wave is done with K (and Q): copy the next position's K (and Q)
+    barrier_keep_vm();
+    issue_kq(nxt, nxt_first);
+
+    if (active) {
+      // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one query's scores
+      float mt = -INFINITY;
+      if (r0 + LP <= len) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float sc = sacc[t][r];
+            if (key >= len) sc += mask_raw;     // (1 - mask) * -10000   (modelling.py:452)
+            if (key >= Lb) sc = -INFINITY;      // not a key at all (tile padding / rows that do not exist)
+            sacc[t][r] = sc;
+            mt = fmaxf(mt, sc);
+          }
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = exp2_neg((m_run - m_new) * s_scale);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
+      const float nm = __builtin_fmaf(-m_new, s_scale, 10.0f);   // + log2(PS): p' = PS * 2^((u - m) * s_scale)
+      static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pexp = exp2_neg(__builtin_fmaf(sacc[t][r], s_scale, nm));
+          sacc[t][r] = pexp;
+          psum += pexp;
+        }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;  // carries the factor PS
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    }
+
+    // ---- [C] V(p) landed.  Younger: the K (+ Q) pieces just issued.
+    if (SAFE) FD_WAIT_VM(0);
+    else if (nxt_first) FD_WAIT_VM(G::KW + G::QW);
+    else FD_WAIT_VM(G::KW);
+    barrier_keep_vm();
+
+    if (active) {
+      // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],  B = P (registers),
+      //                   key(c, half, j) = 32 t + 16 c + 8 (j>>2) + 4 half + (j&3)   (the C/D row map)
+      const unsigned char* vrow = Vt + (size_t)l31 * VROW;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f16x8 ph, pl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xs = sacc[t][8 * c + j];
+            const _Float16 hv = (_Float16)xs;
+            ph[j] = hv;
+            pl[j] = (_Float16)(xs - (float)hv);
+          }
+          const int kb = 2 * (32 * t + 16 * c + 4 * half);
+          const u32x2 vh0 = *reinterpret_cast<const u32x2*>(vrow + kb);
+          const u32x2 vh1 = *reinterpret_cast<const u32x2*>(vrow + kb + 16);
+          const u32x2 vl0 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb);
+          const u32x2 vl1 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb + 16);
+          const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
+          const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
+          const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc, 0, 0, 0);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc, 0, 0, 0);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc, 0, 0, 0);
+        }
+    }
+
+    // ---- [D] every wave is done with V: copy the next position's V
+    barrier_keep_vm();
+    issue_v(nxt);
+
+    const bool item_ends = kt + 1 >= cur.nkt;
+    if (item_ends) {
+      // ctx[row0 + query][head h block] = O^T[d][query] / l_run: register r = 4q + e <-> d = 8q + 4 half + e (quad layout)
+      const int l = l0 + l31;
+      const bool ok = active && l < nrows;
+      const float onorm = ok ? 1.0f / (p.v_scale * l_run) : 0.f;  // l_run and the accumulator both carry PS
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = ok ? oacc[r] * onorm : 0.f;
+      unsigned char* dst = ok ? p.ctx + ((size_t)(row0 + l) * H + h) * 128 : p.trash;
+      store_block(dst, o, p.ctx_scale, half, true);
+    }
+    stored_prev = item_ends;
+    if (done) break;
+    cur = nxt;
+    done = is_last(cur);
+    advance(nxt);
+  }
+  FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
+}
+
+template <int T, bool REL>
+static void launch(const AttnImgArgs& p, hipStream_t s) {
+  using G = Geo<T>;
+  constexpr int smem = REL ? G::SMEM_REL : G::SMEM_ABS;
+  static const bool safe = [] { const char* e = getenv("FDMI_ATTN_SAFE"); return e && atoi(e) != 0; }();
+  static bool attr_set[64] = {false};
+  static int n_cu[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipDeviceProp_t prop;
+    n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    attr_set[dev] = true;
+  }
+  const int nitems = p.B * p.H * p.NKT;
+  int grid = 2 * n_cu[dev];  // two 4-wave workgroups per CU (registers: 2 waves per SIMD)
+  if (grid > nitems) grid = nitems;
+  if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, true>), dim3(grid), dim3(256), smem, s, p);
+  else hipLaunchKernelGGL((attn_img_kernel<T, REL, false>), dim3(grid), dim3(256), smem, s, p);
+}
+
+}  // namespace ai
+
+bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s) {
+  if (L < 1) return false;
+  const int T = L > 128 ? 4 : (L + 31) / 32;  // keys per tile = 32 T; L > 128: 128-key tiles, online softmax
+  const bool rel = p.demb != nullptr;
+#define FD_ATTN_IMG_CASE(TT)                       \
+  case TT:                                         \
+    if (rel) ai::launch<TT, true>(p, s);           \
+    else ai::launch<TT, false>(p, s);              \
+    break;
+  switch (T) {
+    FD_ATTN_IMG_CASE(1)
+    FD_ATTN_IMG_CASE(2)
+    FD_ATTN_IMG_CASE(3)
+    FD_ATTN_IMG_CASE(4)
+  }
+#undef FD_ATTN_IMG_CASE
+  return true;
+}
+
+}  // namespace fdmi

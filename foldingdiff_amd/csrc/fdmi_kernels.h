@@ -8,6 +8,7 @@ namespace fdmi {
 
 constexpr int kHeadDim = 32;   // d_model / n_heads, fixed by the MFMA tilings
 constexpr int kMaxFeat = 16;   // F <= 16 (reference feature sets have 3..9)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // ---- epilogues of the token GEMM  C[M,N] = A[M,K] * W[N,K]^T + bias[N] ----
 enum GemmEpilogue {
@@ -120,5 +121,85 @@ void launch_step_advance(int* t_dev, hipStream_t s);
 // out[i] = Philox normal for (seed, t, element i of [B][L][F] with seq_offset)
 void launch_philox_fill(float* out, unsigned long long seed, int t, long long seq_offset, int B, int L, int F,
                         hipStream_t s);
+
+// ================================================================== row-image path (FD_PREC_F16X3)
+// Activations live in HBM as fp16 hi|lo row images (img_common.h); see gemm_img.hip / attention_img.hip /
+// rowwise_img.hip.  Token rows: sequences start at multiples of 8 rows; `rowinfo[row]` = (sequence, position)
+// or (-1, -1) for padding rows; `dims` (device) = {rows, rows rounded up to 128}.  Every kernel is persistent /
+// grid-stride and reads the row counts from `dims`, so a captured graph serves any lengths of one (B, L).
+enum GemmImgEpilogue { EPI_IMG_GELU = 0, EPI_IMG_LN = 1, EPI_IMG_QK = 2, EPI_IMG_VT = 3, EPI_IMG_BIAS = 4 /* plain bias: test hook */ };
+
+struct GemmImgArgs {
+  const unsigned char* A;      // activation image [rows128][K/32][128 B]
+  const unsigned char* W;      // weight image [N rounded up to 384][K/32][128 B] (zero padded)
+  const float* bias;           // [N]
+  const float* gamma;          // [N]   EPI_IMG_LN
+  const float* beta;           // [N]   EPI_IMG_LN
+  const unsigned char* resid;  // image [rows128][N/32]   EPI_IMG_LN
+  unsigned char* out;          // image [rows128][N/32]   EPI_IMG_GELU / EPI_IMG_LN
+  unsigned char* qbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK
+  unsigned char* kbuf;         // [B][H][LTOT][144 B]     EPI_IMG_QK
+  unsigned char* vbuf;         // [B][H][NKT][32][4 LPK + 8 B]   EPI_IMG_VT
+  unsigned char* trash;        // >= 256 B scratch line for the stores of padding rows
+  const int2* rowinfo;
+  const int* dims;
+  int N, K;                    // valid output columns (multiple of 32), reduction length (multiple of 32)
+  int H, LPK, LTOT, NKT;       // heads; keys per key tile; NKT * LPK; key tiles
+  float acc_scale;             // 1 / (scale of A * scale of W)
+  float out_scale;             // scale of the output image (GELU / LN)
+  float resid_inv;             // 1 / scale of the residual image
+  float eps;                   // LayerNorm eps
+  float q_scale, k_scale, v_scale;
+};
+// max_rows bounds the grid (B * ceil8(L) of the workspace); the kernel reads the actual count from p.dims.
+void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s);
+
+struct AttnImgArgs {
+  const unsigned char* qbuf;
+  const unsigned char* kbuf;
+  const unsigned char* vbuf;
+  const u32x4_t* demb;         // distance table image [2 maxpos - 1][128 B], or null (absolute positions)
+  const int* lens;             // [B] unmasked keys per sequence
+  const int* nrow;             // [B] positions that are rows at all (L, or lens[b] when packed)
+  const int* seq_row0;         // [B + 1] first token row of each sequence
+  unsigned char* ctx;          // image [rows128][H][128 B]
+  unsigned char* trash;
+  int B, H, LTOT, NKT, maxpos;
+  float q_scale, k_scale, v_scale, ctx_scale;
+  float r_scale;               // k_scale / scale of the distance table
+};
+bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s);
+
+struct EmbedImgArgs {
+  const float* x;              // [B][L][F]
+  const float* w_in; const float* b_in; const float* pos_emb; const float* gamma; const float* beta;
+  const float* time_table;
+  int* tslot;                  // [0]: step index of this step (host / head_update_img write it), [1]: copy for the step's other kernels
+  const int2* rowinfo; const int* nrow; const int* dims;
+  unsigned char* h;            // image [rows128][d/32]
+  int L, F, d;
+  float eps, out_scale;
+};
+void launch_embed_img(const EmbedImgArgs& a, int max_rows, hipStream_t s);
+
+struct HeadImgArgs {
+  const unsigned char* g;      // image [rows128][d/32]: head activation (mlp decoder) or final hidden state (linear)
+  float g_inv;                 // 1 / its scale
+  const int2* rowinfo; const int* nrow; const int* dims;
+  int* tslot;
+  int* flag;                   // bit 0 set when a non-finite prediction was seen
+  int advance;                 // write tslot[0] = t - 1 at the end (the sampling loop)
+};
+// UpdateArgs: M = B * L (elements of one state / F), x / eps / noise / hist in the [B][L][F] layout.
+void launch_head_update_img(const UpdateArgs& a, const HeadImgArgs& ia, int max_rows, hipStream_t s);
+
+void launch_build_rows(const int* lens, int B, int L, int packed, int cap, int* seq_row0, int* nrow, int2* rowinfo,
+                       int* dims, hipStream_t s);
+// fp32 [src_rows][K] -> image [rows][K/32] (rows >= src_rows are zero rows), value * scale = hi + lo; and back
+void launch_f32_to_img(const float* src, void* dst, long long rows, int K, long long src_rows, float scale, hipStream_t s);
+void launch_img_to_f32(const void* src, float* dst, long long rows, int K, float scale, hipStream_t s);
+// debug: q / k rows or v^T blocks -> fp32 [BH][LTOT][32]
+void launch_qkv_unpack(const void* src, float* dst, long long BH, int LTOT, int LP, int rowbytes, int is_vt, float scale,
+                       hipStream_t s);
 
 }  // namespace fdmi

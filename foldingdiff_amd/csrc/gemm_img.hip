@@ -1,0 +1,469 @@
+// Token GEMMs of the encoder on row images (img_common.h): fp32-class accuracy on the fp16 matrix cores.
+//
+//   C[M,N] = A[M,K] * W[N,K]^T + bias[N]   then one of four epilogues
+//     EPI_QK    q | k of HF BertSelfAttention (transformers 4.11.3, called from foldingdiff/modelling.py:473-480)
+//               scattered per (sequence, head) in the layouts the attention kernel DMA-copies into LDS
+//     EPI_VT    v, written transposed per (sequence, head, key tile): [d][hi keys | lo keys]
+//     EPI_GELU  BertIntermediate.dense / AnglesPredictor.dense1 + exact-erf GELU (modelling.py:195-196, :203-205)
+//     EPI_LN    BertSelfOutput / BertOutput: LayerNorm(dense(x) + residual)
+//
+// Arithmetic: a product a*w is  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi  on three v_mfma_f32_32x32x16_f16 into one
+// fp32 accumulator (fp16 x fp16 products are exact in fp32; the dropped lo*lo term is 2^-22 relative).
+//
+// What is different from a register-staged split GEMM:
+//  * BOTH operands already live in HBM as hi|lo row images (activations are written that way by every
+//    producer epilogue), so a k-tile (32 k = one 128-byte block per row) is staged with LDS-DMA
+//    (buffer_load_dwordx4 ... lds): no VGPR round trip, no split arithmetic, no ds_write in the k-loop.
+//    The LDS image is lane-linear; the bank swizzle (16-byte unit ^= (row >> 1) & 7) is applied to the
+//    per-lane SOURCE address and to the fragment reads.
+//  * 128 (M) x 384 (N) block, 8 waves as 2 (M) x 4 (N), wave tile 64 x 96 = 2 x 3 MFMA tiles (96 accumulators),
+//    18 MFMAs per 10 fragment fetches.  W ring: 2 stages (always L2 hits), A ring: 3 stages (the HBM stream,
+//    issued two k-tiles ahead), ONE workgroup barrier per k-tile, counted s_waitcnt vmcnt (never 0 in the loop).
+//  * persistent: one workgroup per CU walks an XCD-aware tile list; the (tile, k-tile) pairs form one
+//    continuous stream, so the next tile's operands are in flight during the epilogue.
+//  * "swapped" MFMA form (D^T = W A^T; all epilogues but EPI_VT): a lane owns ONE token row and 16 columns, so
+//    LayerNorm statistics are in-lane sums, and the output block is written with four 16-byte stores per
+//    32 x 32 tile after a half-wave register exchange (img_common.h) instead of sixteen 4-byte stores.
+#include <cstdlib>
+
+#include "fdmi_kernels.h"
+#include "img_common.h"
+
+namespace fdmi {
+namespace gi {
+
+constexpr int BM = 128, BN = 384, NTHR = 512;
+constexpr int W_STAGE = BN * 128, A_STAGE = BM * 128;           // bytes per k-tile stage
+constexpr int NWS = 2, NAS = 3;
+constexpr int OFF_A = NWS * W_STAGE;                            //  98,304
+constexpr int OFF_PAR = OFF_A + NAS * A_STAGE;                  // 147,456: bias | gamma | beta (EPI_LN)
+constexpr int OFF_RED = OFF_PAR + 3 * BN * 4;                   // 152,064: 2 x part[128][4]
+constexpr int SMEM = OFF_RED + 2 * BM * 4 * 4;                  // 156,160 B
+
+__device__ __forceinline__ float erf_rational(float x) {  // (13,8) rational minimax on [-4,4], |err| <= 4.5e-7 (tests/test_host.py)
+  x = __builtin_fminf(__builtin_fmaxf(x, -4.0f), 4.0f);
+  const float x2 = x * x;
+  float p = -2.72614225801306e-10f;
+  p = __builtin_fmaf(p, x2, 2.77068142495902e-08f);
+  p = __builtin_fmaf(p, x2, -2.10102402082508e-06f);
+  p = __builtin_fmaf(p, x2, -5.69250639462346e-05f);
+  p = __builtin_fmaf(p, x2, -7.34990630326855e-04f);
+  p = __builtin_fmaf(p, x2, -2.95459980854025e-03f);
+  p = __builtin_fmaf(p, x2, -1.60960333262415e-02f);
+  float q = -1.45660718464996e-05f;
+  q = __builtin_fmaf(q, x2, -2.13374055278905e-04f);
+  q = __builtin_fmaf(q, x2, -1.68282697438203e-03f);
+  q = __builtin_fmaf(q, x2, -7.37332916720468e-03f);
+  q = __builtin_fmaf(q, x2, -1.42647390514189e-02f);
+  return (p * x) * __builtin_amdgcn_rcpf(q);
+}
+__device__ __forceinline__ float gelu_erf(float x) {  // HF "gelu": 0.5 x (1 + erf(x / sqrt 2))
+  const float h = 0.5f * x;
+  return __builtin_fmaf(h, erf_rational(x * 0.70710678118654752440f), h);
+}
+
+template <int EPI, bool SWAP>
+__global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wid & 3, wm = wid >> 2;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int nk = p.K >> 5, rb = nk * 128;                 // k-tiles; bytes per image row (A and W share K)
+  const int Mp = p.dims[1];
+  const int tiles_n = (p.N + BN - 1) / BN, ntiles = (Mp / BM) * tiles_n;
+  // tiles are dealt XCD-aware, n fastest: the workgroups of one XCD (blockIdx % 8) take neighbouring tiles at
+  // the same time, so the column tiles of one A panel meet in that XCD's L2
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int tlo = (int)((long long)ntiles * xcd / 8), thi = (int)((long long)ntiles * (xcd + 1) / 8);
+  const int first = tlo + jx, stride = per;
+  const int cnt = first < thi ? (thi - first + stride - 1) / stride : 0;
+  if (cnt == 0) return;
+  const int G = cnt * nk;  // stream positions
+
+  if constexpr (EPI == EPI_IMG_LN) {
+    float* par = reinterpret_cast<float*>(smem + OFF_PAR);
+    for (int i = tid; i < BN; i += NTHR) {
+      const bool ok = i < p.N;
+      par[i] = ok ? p.bias[i] : 0.f;
+      par[BN + i] = ok ? p.gamma[i] : 0.f;
+      par[2 * BN + i] = ok ? p.beta[i] : 0.f;
+    }
+  }
+
+  // ---- staging: per k-tile 48 W chunks + 16 A chunks of 1 KiB (8 rows x 128 B); wave w issues W chunks
+  // w + 8 i (i < 6) and A chunks w + 8 i (i < 2).  Lane -> (row = 8 chunk + lane / 8, LDS unit = lane % 8),
+  // fetched from source unit (lane % 8) ^ swizzle(row).
+  const int voff = (8 * wid + (lane >> 3)) * rb + (((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) << 4);
+  int iw_ti = 0, iw_kt = 0, ia_ti = 0, ia_kt = 0;  // next stream position to issue (W ring / A ring)
+  int iw_slot = 0, ia_slot = 0;
+  auto tile_mn = [&](int ti, int& m0, int& n0) {
+    const int tile = first + ti * stride;
+    m0 = (tile / tiles_n) * BM;
+    n0 = (tile - (tile / tiles_n) * tiles_n) * BN;
+  };
+  int iw_n0, ia_m0;  // tile origin of the issue cursors (recomputed only when the cursor enters a new tile)
+  tile_mn(0, ia_m0, iw_n0);
+  auto issue_w = [&]() {
+    const int n0 = iw_n0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(p.W) + (size_t)n0 * rb, 0, BN * rb, 0x00020000);
+    lds_ptr_t dst = (lds_ptr_t)(smem) + iw_slot * W_STAGE + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma16(rs, dst + i * 8192, voff, iw_kt * 128 + i * 64 * rb);
+    iw_slot ^= 1;
+    if (iw_ti * nk + iw_kt + 1 < G) {  // past the end: re-issue the last position (lands in a free slot, never read)
+      if (++iw_kt == nk) {
+        iw_kt = 0;
+        ++iw_ti;
+        int mm;
+        tile_mn(iw_ti, mm, iw_n0);
+      }
+    }
+  };
+  auto issue_a = [&]() {
+    const int m0 = ia_m0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(p.A) + (size_t)m0 * rb, 0, BM * rb, 0x00020000);
+    lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + ia_slot * A_STAGE + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(rs, dst + i * 8192, voff, ia_kt * 128 + i * 64 * rb);
+    ia_slot = ia_slot == NAS - 1 ? 0 : ia_slot + 1;
+    if (ia_ti * nk + ia_kt + 1 < G) {
+      if (++ia_kt == nk) {
+        ia_kt = 0;
+        ++ia_ti;
+        int nn;
+        tile_mn(ia_ti, ia_m0, nn);
+      }
+    }
+  };
+
+  // ---- fragment reads: rows wn*96 + 32 jn + l31 (W) / wm*64 + 32 im + l31 (A); every such row has
+  // swizzle (l31 >> 1) & 7, so a lane needs four unit offsets per operand: [k16 step c][plane]
+  const int sw = (l31 >> 1) & 7;
+  int wrd[2][2], ard[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int u = ((2 * c + half + 4 * pl) ^ sw) << 4;
+      wrd[c][pl] = (wn * 96 + l31) * 128 + u;
+      ard[c][pl] = OFF_A + (wm * 64 + l31) * 128 + u;
+    }
+
+  f32x16 acc[3][2];  // [jn][im]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int jn = 0; jn < 3; ++jn)
+#pragma unroll
+      for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jn][im][r] = 0.f;
+  };
+  zero_acc();
+
+  auto compute = [&](int wslot, int aslot) {
+    const unsigned char* wb = smem + wslot * W_STAGE;
+    const unsigned char* ab = smem + aslot * A_STAGE;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f16x8 wh[3], wl[3], ah[2], al[2];
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn) {
+        wh[jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][0] + jn * 4096);
+        wl[jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][1] + jn * 4096);
+      }
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+        ah[im] = *reinterpret_cast<const f16x8*>(ab + ard[c][0] + im * 4096);
+        al[im] = *reinterpret_cast<const f16x8*>(ab + ard[c][1] + im * 4096);
+      }
+      // term by term over the six tiles: consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn)
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+          acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], ah[im], acc[jn][im], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], wh[jn], acc[jn][im], 0, 0, 0);
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn)
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+          acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], al[im], acc[jn][im], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[im], wh[jn], acc[jn][im], 0, 0, 0);
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn)
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+          acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[jn], ah[im], acc[jn][im], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], wl[jn], acc[jn][im], 0, 0, 0);
+    }
+  };
+
+  // ---- epilogues.  SWAP form: lane (l31, half) owns token row  m0 + wm*64 + 32 im + l31  and, per MFMA tile jn,
+  // the columns  n0 + wn*96 + 32 jn + 8q + 4 half + e  (register r = 4q + e): the quad layout of img_common.h.
+  // Returns the wave's number of column blocks inside N (every such block issues exactly 8 store instructions:
+  // pad rows are redirected to a scratch line instead of being predicated off, so the count is exact).
+  auto epilogue = [&](int ti) -> int {
+    int m0, n0;
+    tile_mn(ti, m0, n0);
+    const float os = p.acc_scale;
+    int nv = 0;
+    if constexpr (EPI == EPI_IMG_GELU || EPI == EPI_IMG_BIAS) {
+      const int nb = p.N >> 5;  // blocks per output row
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn) {
+        const int cb = (n0 >> 5) + wn * 3 + jn;  // wave-uniform
+        if (cb >= nb) continue;
+        ++nv;
+        float4 b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * q + 4 * half);
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+          const int mrow = m0 + wm * 64 + im * 32 + l31;
+          float o[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[4 * q + 0] = __builtin_fmaf(acc[jn][im][4 * q + 0], os, b4[q].x);
+            o[4 * q + 1] = __builtin_fmaf(acc[jn][im][4 * q + 1], os, b4[q].y);
+            o[4 * q + 2] = __builtin_fmaf(acc[jn][im][4 * q + 2], os, b4[q].z);
+            o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3], os, b4[q].w);
+          }
+          if constexpr (EPI == EPI_IMG_GELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = gelu_erf(o[r]);
+          }
+          store_block(p.out + ((size_t)mrow * nb + cb) * 128, o, p.out_scale, half, true);
+        }
+      }
+    } else if constexpr (EPI == EPI_IMG_QK) {
+      const int H = p.H;
+      int2 ri[2];
+#pragma unroll
+      for (int im = 0; im < 2; ++im) ri[im] = p.rowinfo[m0 + wm * 64 + im * 32 + l31];
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn) {
+        const int cb = (n0 >> 5) + wn * 3 + jn;  // wave-uniform: block of the [q | k] column space
+        if (cb >= 2 * H) continue;
+        ++nv;
+        const int isk = cb >= H ? 1 : 0, h = cb - isk * H;
+        float4 b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * q + 4 * half);
+        const float sc = isk ? p.k_scale : p.q_scale;
+        const size_t pitch = isk ? (size_t)p.LTOT * 144 : (size_t)p.LTOT * 128;
+        const size_t rbytes = isk ? 144 : 128;
+        unsigned char* basep = isk ? p.kbuf : p.qbuf;
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+          float o[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[4 * q + 0] = __builtin_fmaf(acc[jn][im][4 * q + 0], os, b4[q].x);
+            o[4 * q + 1] = __builtin_fmaf(acc[jn][im][4 * q + 1], os, b4[q].y);
+            o[4 * q + 2] = __builtin_fmaf(acc[jn][im][4 * q + 2], os, b4[q].z);
+            o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3], os, b4[q].w);
+          }
+          const bool ok = ri[im].x >= 0;
+          unsigned char* dst = ok ? basep + ((size_t)ri[im].x * H + h) * pitch + (size_t)ri[im].y * rbytes : p.trash;
+          store_block(dst, o, sc, half, true);
+        }
+      }
+    } else if constexpr (EPI == EPI_IMG_VT) {
+      // normal MFMA form: lane = column (d = l31 of head cb), register r = 4q + e <-> token row 8q + 4 half + e of the
+      // 32-row MFMA tile.  After the exchange the lower lane holds token octets 0, 1 and the upper lane 2, 3 of the
+      // tile; sequences start at multiples of 8 rows, so an octet never straddles two sequences.
+      const int H = p.H, LP = p.LPK, vrow = 4 * LP + 8;
+#pragma unroll
+      for (int jn = 0; jn < 3; ++jn) {
+        const int cb = (n0 >> 5) + wn * 3 + jn;
+        if (cb >= H) continue;
+        ++nv;
+        const float bz = p.bias[cb * 32 + l31];
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+          float o[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(acc[jn][im][r], os, bz);
+          u32x4 hh[2], ll[2];
+          pack_block(o, p.v_scale, hh[0], hh[1], ll[0], ll[1]);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int2 ri = p.rowinfo[m0 + wm * 64 + im * 32 + 16 * half + 8 * u];
+            const bool ok = ri.x >= 0;
+            const int lpos = ok ? ri.y : 0;
+            const int kt = lpos / LP, kl = lpos - kt * LP;
+            unsigned char* row = ok ? p.vbuf + ((((size_t)ri.x * H + cb) * p.NKT + kt) * 32 + l31) * vrow + 2 * kl : p.trash;
+            *reinterpret_cast<u32x4*>(row) = hh[u];
+            *reinterpret_cast<u32x4*>(row + (ok ? 2 * LP : 64)) = ll[u];
+          }
+        }
+      }
+    } else {  // EPI_IMG_LN
+      const int N = p.N, nb = N >> 5;
+      const float* par = reinterpret_cast<const float*>(smem + OFF_PAR);
+      float* red = reinterpret_cast<float*>(smem + OFF_RED);
+      const float inv_n = 1.0f / (float)N;
+      float s[2] = {0.f, 0.f};
+      // v = acc / (a_scale w_scale) + bias + residual (read back from its image)
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+        const int mrow = m0 + wm * 64 + im * 32 + l31;
+        const unsigned char* rrow = p.resid + (size_t)mrow * nb * 128;
+#pragma unroll
+        for (int jn = 0; jn < 3; ++jn) {
+          const int cb = wn * 3 + jn;
+          if (cb >= nb) {  // columns beyond N (d_model < 384): contribute nothing
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jn][im][r] = 0.f;
+            continue;
+          }
+          float rv[16];
+          load_block(rrow + cb * 128, rv, p.resid_inv, half);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(par + cb * 32 + 8 * q + 4 * half);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = __builtin_fmaf(acc[jn][im][4 * q + e], os, bb[e]) + rv[4 * q + e];
+              acc[jn][im][4 * q + e] = v;
+              s[im] += v;
+            }
+          }
+        }
+      }
+      // row sums: in-lane (48 columns) + the other half-wave + the four N-waves through LDS, fixed order
+      auto block_sum = [&](float (&t)[2], float* part) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+          t[im] += __shfl_xor(t[im], 32);
+          if (half == 0) part[(wm * 64 + im * 32 + l31) * 4 + wn] = t[im];
+        }
+        barrier_keep_vm();
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+          const float4 q4 = *reinterpret_cast<const float4*>(part + (wm * 64 + im * 32 + l31) * 4);
+          t[im] = (q4.x + q4.y) + (q4.z + q4.w);
+        }
+      };
+      block_sum(s, red);
+      float t2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+        const float mean = s[im] * inv_n;
+#pragma unroll
+        for (int jn = 0; jn < 3; ++jn) {
+          if (wn * 3 + jn >= nb) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float dl = acc[jn][im][r] - mean;
+            acc[jn][im][r] = dl;
+            t2[im] += dl * dl;
+          }
+        }
+      }
+      block_sum(t2, red + BM * 4);
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+        const float rstd = 1.0f / sqrtf(t2[im] * inv_n + p.eps);
+        const int mrow = m0 + wm * 64 + im * 32 + l31;
+        unsigned char* orow = p.out + (size_t)mrow * nb * 128;
+#pragma unroll
+        for (int jn = 0; jn < 3; ++jn) {
+          const int cb = wn * 3 + jn;
+          if (cb >= nb) continue;
+          if (im == 0) ++nv;
+          float o[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 g4 = *reinterpret_cast<const float4*>(par + BN + cb * 32 + 8 * q + 4 * half);
+            const float4 e4 = *reinterpret_cast<const float4*>(par + 2 * BN + cb * 32 + 8 * q + 4 * half);
+            o[4 * q + 0] = acc[jn][im][4 * q + 0] * rstd * g4.x + e4.x;
+            o[4 * q + 1] = acc[jn][im][4 * q + 1] * rstd * g4.y + e4.y;
+            o[4 * q + 2] = acc[jn][im][4 * q + 2] * rstd * g4.z + e4.z;
+            o[4 * q + 3] = acc[jn][im][4 * q + 3] * rstd * g4.w + e4.w;
+          }
+          store_block(orow + cb * 128, o, p.out_scale, half, true);
+        }
+      }
+    }
+    return nv;
+  };
+
+  // ---- the stream.  In-order vmcnt bookkeeping per wave (DMA pieces: W 6, A 2 per position):
+  //   prologue      A(0) W(0) A(1)
+  //   iteration g   [wait W(g), A(g)] [barrier] W(g+1) A(g+2) compute(g) (+ epilogue stores after the last k-tile)
+  // At the wait of iteration g the younger operations are A(g+1) (2) and, right after an epilogue, that tile's
+  // stores: vmcnt(2) / vmcnt(2 + 8 per stored column block) keeps all of them in flight.  The barrier also tells
+  // every wave that compute(g-1) is over, which frees W slot (g+1) & 1 and A slot (g+2) % 3.
+  issue_a();
+  issue_w();
+  issue_a();
+  int cw = 0, ca = 0;  // slots of the position being computed
+  int nv_prev = -1;    // column blocks stored by the previous tile's epilogue (-1: none yet)
+  for (int ti = 0; ti < cnt; ++ti) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt == 0 && nv_prev > 0) {
+        if (nv_prev == 3) FD_WAIT_VM(2 + 24);
+        else if (nv_prev == 2) FD_WAIT_VM(2 + 16);
+        else FD_WAIT_VM(2 + 8);
+      } else {
+        FD_WAIT_VM(2);
+      }
+      barrier_keep_vm();  // (also publishes the EPI_LN parameter image before the first epilogue)
+      issue_w();
+      issue_a();
+      compute(cw, ca);
+      cw ^= 1;
+      ca = ca == NAS - 1 ? 0 : ca + 1;
+    }
+    nv_prev = epilogue(ti);
+    zero_acc();
+  }
+  FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
+}
+
+static int n_cu_of_current_device() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    hipDeviceProp_t prop;
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cached[dev];
+}
+
+template <int EPI, bool SWAP>
+static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set[dev] = true;
+  }
+  const int ntiles_max = ((max_rows + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  int grid = n_cu_of_current_device() / 8 * 8;
+  if (grid > ntiles_max) grid = (ntiles_max + 7) / 8 * 8;
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP>), dim3(grid), dim3(NTHR), SMEM, s, p);
+}
+
+}  // namespace gi
+
+void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s) {
+  switch (epilogue) {
+    case EPI_IMG_GELU: gi::launch<EPI_IMG_GELU, true>(p, max_rows, s); break;
+    case EPI_IMG_LN: gi::launch<EPI_IMG_LN, true>(p, max_rows, s); break;
+    case EPI_IMG_QK: gi::launch<EPI_IMG_QK, true>(p, max_rows, s); break;
+    case EPI_IMG_BIAS: gi::launch<EPI_IMG_BIAS, true>(p, max_rows, s); break;
+    default: gi::launch<EPI_IMG_VT, false>(p, max_rows, s); break;
+  }
+}
+
+}  // namespace fdmi

@@ -39,7 +39,8 @@ enum {
   FD_E_STATE = -2,       /* call order (e.g. sample before finalize)    */
   FD_E_MISSING = -3,     /* a required weight was never set             */
   FD_E_HIP = -4,         /* HIP runtime error (message has hipGetErrorString) */
-  FD_E_UNSUPPORTED = -5  /* valid in the reference, not implemented here */
+  FD_E_UNSUPPORTED = -5, /* valid in the reference, not implemented here */
+  FD_E_NONFINITE = -6    /* the model produced inf / NaN (e.g. corrupt weights); results are not usable */
 };
 
 /* config.position_embedding_type (config.json; modelling.py:138-149, HF BertSelfAttention) */
@@ -114,7 +115,11 @@ void fd_destroy(fd_model* m);
  *   "use_graph"  1 (default): the per-step kernel sequence is replayed from a hipGraph;
  *                0: eager launches.
  *   "attn_f16"   with FD_PREC_F16X3 only -- 1 (default): attention contractions on the fp16x3
- *                kernel too; 0: keep the exact-fp32 attention kernel. */
+ *                kernel too; 0: keep the exact-fp32 attention kernel.
+ *   "varlen"     fd_sample / fd_sample_dev with FD_PREC_F16X3: 1 = positions >= lens[b] are not computed at all
+ *                (the reference computes them and sampling.sample cuts them away, sampling.py:56-58, :201-203);
+ *                positions < lens[b] are bit-identical either way.  Padded positions of `out` then keep x_init.
+ *                0 (default): every position evolves as in the reference's p_sample_loop. */
 int fd_set_option(fd_model* m, const char* name, int value);
 
 /* ---- parity hooks ---- */
@@ -207,6 +212,17 @@ int fd_profile_get(fd_model* m, int i, const char** name, double* total_ms, int6
 
 /* Block until all work queued on the model's own stream is done. */
 int fd_synchronize(fd_model* m);
+
+/* Failure detection for the asynchronous entry point: FD_E_NONFINITE if any reverse step since the last check
+ * predicted a non-finite noise value (the host-buffer entry points check by themselves).  Call after the work
+ * has completed (fd_synchronize / the caller's stream sync).  The reference has no such guard: a NaN there
+ * silently propagates into the sampled angles (foldingdiff/sampling.py:62-75). */
+int fd_check_finite(fd_model* m);
+
+/* Debug / test aid (FD_PREC_F16X3 only): copy an intermediate of the last step back as float32.  `name`: "h", "a",
+ * "ctx", "g", "g_head", "h_out" ([rows rounded up to 128][width]) or "q", "k", "v" ([B][H][padded L][32]); scales are
+ * those of layer option "debug_layer"; option "debug_stop" = n ends a step after n kernel launches. */
+int fd_debug_read(fd_model* m, const char* name, float* out, int64_t n_floats);
 
 const char* fd_last_error(void);
 
