@@ -126,6 +126,7 @@ struct fd_model {
   int fuse_ln = -1;  // -1 auto: LN-fused GEMMs with fp16x3 (measured 9.37 vs 10.15 ms/step), not with fp32 (slower there)
   int use_graph = 1;
   int attn_f16 = 1;  // with FD_PREC_F16X3: attention on the fp16x3 kernel (0: keep the fp32-MFMA one)
+  unsigned long long* stamps = nullptr;  // debug cycle stamps (FDMI_STAMPS=1): gemm [5][8][64][6] then attention [4][64][8]
   int debug_stop = 0;  // row-image path: stop a step after this many launches (debug dumps; 0 = off)
   int debug_layer = 0; // layer whose scales fd_debug_read uses
   int varlen = 0;    // row-image path: only the first lens[b] positions of a sequence are token rows
@@ -314,8 +315,9 @@ int ensure_ws(fd_model* m, int B, int L) {
     double* by = m->prof_bytes;
     const bool img = m->img;
     fl[KC_EMBED] = 2 * Md * F * dd;            by[KC_EMBED] = 4 * (Md * F + Md * dd);
-    fl[KC_GEMM_QKV] = 2 * Md * (img ? 2 : 3) * dd * dd;
-    by[KC_GEMM_QKV] = 4 * (Md * dd + (img ? 2 : 3) * dd * dd + Md * (img ? 2 : 3) * dd);
+    const int qn = img ? 2 : 3;  // the row-image path computes V (transposed) in its own launch
+    fl[KC_GEMM_QKV] = 2 * Md * qn * dd * dd;
+    by[KC_GEMM_QKV] = 4 * (Md * dd + qn * dd * dd + Md * qn * dd);
     fl[KC_GEMM_V] = 2 * Md * dd * dd;          by[KC_GEMM_V] = 4 * (2 * Md * dd + dd * dd);
     fl[KC_ATTN] = 6 * Ld * dd * Md;            by[KC_ATTN] = 4 * (Md * 3 * dd + Md * dd);
     fl[KC_GEMM_OUT] = 2 * Md * dd * dd;        by[KC_GEMM_OUT] = 4 * (3 * Md * dd + dd * dd);
@@ -377,7 +379,7 @@ int ensure_ws(fd_model* m, int B, int L) {
     HIP_TRY(alz((void**)&w.gimg, cap * gmax * 4));
     HIP_TRY(alz((void**)&w.qbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 144));
-    HIP_TRY(alz((void**)&w.vbuf, BH * w.NKT * 32 * (size_t)(4 * w.LPK + 8)));
+    HIP_TRY(alz((void**)&w.vbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.trash, 1024));
     HIP_TRY(alz((void**)&w.rowinfo, cap * sizeof(int2)));
     HIP_TRY(alz((void**)&w.seq_row0, ((size_t)B + 1) * 4));
@@ -588,9 +590,15 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     PROF(KC_EMBED, launch_embed_img(e, max_rows, s));
       DBG_STOP();
   }
+  static const bool want_stamps = [] { const char* e = getenv("FDMI_STAMPS"); return e && atoi(e) != 0; }();
+  if (want_stamps && !m->stamps) {
+    HIP_TRY(hipMalloc((void**)&m->stamps, (5 * 8 * 64 * 6 + 4 * 64 * 8) * 8));
+    HIP_TRY(hipMemset(m->stamps, 0, (5 * 8 * 64 * 6 + 4 * 64 * 8) * 8));
+  }
   auto base = [&]() {
     GemmImgArgs g;
     memset(&g, 0, sizeof g);
+    g.stamps = m->stamps;
     g.trash = w.trash; g.rowinfo = w.rowinfo; g.dims = w.dims;
     g.H = H; g.LPK = w.LPK; g.LTOT = w.LTOT; g.NKT = w.NKT;
     g.eps = c.ln_eps;
@@ -600,20 +608,22 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     const LayerDev& lw = m->layers[li];
     const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
     {
-      GemmImgArgs g = base();
-      g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqk_i.p); g.bias = lw.bqk;
-      g.qbuf = w.qbuf; g.kbuf = w.kbuf; g.N = 2 * d; g.K = d;
-      g.acc_scale = 1.0f / (lw.s_h * lw.wqk_i.scale); g.q_scale = lw.s_q; g.k_scale = lw.s_k;
-      PROF(KC_GEMM_QKV, launch_gemm_img(EPI_IMG_QK, g, max_rows, s));
-      DBG_STOP();
-    }
-    {
-      GemmImgArgs g = base();
-      g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wv_i.p); g.bias = lw.bv;
-      g.vbuf = w.vbuf; g.N = d; g.K = d;
-      g.acc_scale = 1.0f / (lw.s_h * lw.wv_i.scale); g.v_scale = lw.s_v;
-      PROF(KC_GEMM_V, launch_gemm_img(EPI_IMG_VT, g, max_rows, s));
-      DBG_STOP();
+      {
+        GemmImgArgs g = base();
+        g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqk_i.p); g.bias = lw.bqk;
+        g.qbuf = w.qbuf; g.kbuf = w.kbuf; g.N = 2 * d; g.K = d;
+        g.acc_scale = 1.0f / (lw.s_h * lw.wqk_i.scale); g.q_scale = lw.s_q; g.k_scale = lw.s_k;
+        PROF(KC_GEMM_QKV, launch_gemm_img(EPI_IMG_QK, g, max_rows, s));
+        DBG_STOP();
+      }
+      {
+        GemmImgArgs g = base();
+        g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wv_i.p); g.bias = lw.bv;
+        g.vbuf = w.vbuf; g.N = d; g.K = d;
+        g.acc_scale = 1.0f / (lw.s_h * lw.wv_i.scale); g.v_scale = lw.s_v;
+        PROF(KC_GEMM_V, launch_gemm_img(EPI_IMG_VT, g, max_rows, s));
+        DBG_STOP();
+      }
     }
     {
       AttnImgArgs a;
@@ -624,6 +634,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       a.B = B; a.H = H; a.LTOT = w.LTOT; a.NKT = w.NKT; a.maxpos = c.max_pos;
       a.q_scale = lw.s_q; a.k_scale = lw.s_k; a.v_scale = lw.s_v; a.ctx_scale = lw.s_v;
       a.r_scale = lw.demb_s.p ? lw.s_k / lw.demb_s.scale : 1.f;
+      a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 : nullptr;
       bool ok = true;
       PROF(KC_ATTN, ok = launch_attention_img(a, L, s));
       if (!ok) return fail(FD_E_UNSUPPORTED, "attention: L=%d", L);
@@ -1547,7 +1558,13 @@ int fd_debug_read(fd_model* m, const char* name, float* out, int64_t n_floats) {
   else if (nm == "q") rc = qkv(w.qbuf, 128, 0, lw.s_q);
   else if (nm == "k") rc = qkv(w.kbuf, 144, 0, lw.s_k);
   else if (nm == "v") rc = qkv(w.vbuf, 0, 1, lw.s_v);
-  else if (nm == "rowinfo") {
+  else if (nm == "stamps") {
+    need = 5 * 8 * 64 * 6 + 4 * 64 * 8;
+    if (n_floats < 2 * need) return fail(FD_E_INVALID, "fd_debug_read(stamps): need %lld floats (uint64 view)", 2 * need);
+    if (!m->stamps) return fail(FD_E_STATE, "no stamps were recorded (FDMI_STAMPS=1)");
+    HIP_TRY(hipMemcpy(out, m->stamps, need * 8, hipMemcpyDeviceToHost));
+    return FD_OK;
+  } else if (nm == "rowinfo") {
     need = 2LL * w.cap;
     if (n_floats < need) return fail(FD_E_INVALID, "fd_debug_read(rowinfo): need %lld", need);
     std::vector<int> t(need);

@@ -5,7 +5,8 @@
 // Inputs are what the QK / V^T GEMM epilogues wrote, already split and already in the LDS layout:
 //     q   [b][h][LTOT rows][128 B]   hi d0-31 | lo d0-31
 //     k   [b][h][LTOT rows][144 B]   hi | lo | 16 B pad      (conflict-free 16-byte operand fetches)
-//     vt  [b][h][key tile][32 d][4 LP + 8 B]   hi keys | lo keys | pad   (V transposed; conflict-free 8-byte fetches)
+//     vt  [b][h][32-key block][32 d][128 B]    V transposed: hi keys | lo keys as sixteen 8-byte units, unit u stored
+//                                               at u ^ ((d >> 1) & 15)  (conflict-free 8-byte operand fetches)
 // so filling LDS is a linear LDS-DMA copy: no VGPR round trip, no split arithmetic, no ds_write.
 //
 // A 4-wave workgroup is persistent over (sequence, head, query group) items and treats the (item, key tile)
@@ -39,8 +40,7 @@ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 template <int T>
 struct Geo {
   static constexpr int LP = 32 * T;
-  static constexpr int VROW = 4 * LP + 8;
-  static constexpr int Q_BYTES = LP * 128, K_BYTES = LP * KROW, V_BYTES = 32 * VROW;
+  static constexpr int Q_BYTES = LP * 128, K_BYTES = LP * KROW, V_BYTES = LP * 128;
   static constexpr int QC = ceil_div(Q_BYTES, 1024), KC = ceil_div(K_BYTES, 1024), VC = ceil_div(V_BYTES, 1024);
   static constexpr int QW = ceil_div(QC, 4), KW = ceil_div(KC, 4), VW = ceil_div(VC, 4);  // DMA pieces per wave
   static constexpr int OFF_Q = 0, OFF_K = OFF_Q + QW * 4 * 1024, OFF_V = OFF_K + KW * 4 * 1024,
@@ -49,10 +49,10 @@ struct Geo {
 };
 
 // SAFE: every wait is vmcnt(0) (debug aid for the counted-wait bookkeeping)
-template <int T, bool REL, bool SAFE>
+template <int T, bool REL, bool SAFE, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
   using G = Geo<T>;
-  constexpr int LP = G::LP, VROW = G::VROW;
+  constexpr int LP = G::LP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem + G::OFF_Q;
   unsigned char* Ks = smem + G::OFF_K;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
   };
   auto issue_v = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
-    copy(p.vbuf + ((bh * p.NKT + s.kt) * 32) * (size_t)VROW, G::V_BYTES, G::VC, G::VW, Vt);
+    copy(p.vbuf + (bh * p.LTOT + (size_t)s.kt * LP) * 128, G::V_BYTES, G::VC, G::VW, Vt);
   };
 
   if ((int)blockIdx.x >= nitems) return;
@@ -119,8 +119,13 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc;
   bool stored_prev = false;  // the previous position ended an item (4 ctx stores are younger than its V copy)
+  const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
+  unsigned long long* st = PROF ? p.stamps + (size_t)wq * 64 * 8 : nullptr;
+  int slot = 0;
+#define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
   for (;;) {
+    FD_STAMP(0);
     const int b = cur.b, h = cur.h, qg = cur.qg, kt = cur.kt, len = cur.len;
     const int row0 = p.seq_row0[b];
     const int nrows = p.seq_row0[b + 1] - row0;  // token rows of the sequence (multiple of 8, >= real rows)
@@ -135,7 +140,9 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
     if (SAFE) FD_WAIT_VM(0);
     else if (stored_prev) FD_WAIT_VM(G::VW + 4);
     else FD_WAIT_VM(G::VW);
+    FD_STAMP(1);
     barrier_keep_vm();
+    FD_STAMP(2);
     if (first_tile) {
       const unsigned char* qrow = Qs + (size_t)(32 * (wq < T ? wq : 0) + l31) * 128;
 #pragma unroll
@@ -226,8 +233,10 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
     }
 
     // ---- [B] every wave is done with K (and Q): copy the next position's K (and Q)
+    FD_STAMP(3);
     barrier_keep_vm();
     issue_kq(nxt, nxt_first);
+    FD_STAMP(4);
 
     if (active) {
       // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one query's scores
@@ -275,12 +284,15 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
     if (SAFE) FD_WAIT_VM(0);
     else if (nxt_first) FD_WAIT_VM(G::KW + G::QW);
     else FD_WAIT_VM(G::KW);
+    FD_STAMP(5);
     barrier_keep_vm();
+    FD_STAMP(6);
 
     if (active) {
       // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],  B = P (registers),
       //                   key(c, half, j) = 32 t + 16 c + 8 (j>>2) + 4 half + (j&3)   (the C/D row map)
-      const unsigned char* vrow = Vt + (size_t)l31 * VROW;
+      const unsigned char* vrow = Vt + (size_t)l31 * 128;
+      const int sz = (l31 >> 1) & 15;
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -293,11 +305,13 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
             ph[j] = hv;
             pl[j] = (_Float16)(xs - (float)hv);
           }
-          const int kb = 2 * (32 * t + 16 * c + 4 * half);
-          const u32x2 vh0 = *reinterpret_cast<const u32x2*>(vrow + kb);
-          const u32x2 vh1 = *reinterpret_cast<const u32x2*>(vrow + kb + 16);
-          const u32x2 vl0 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb);
-          const u32x2 vl1 = *reinterpret_cast<const u32x2*>(vrow + 2 * LP + kb + 16);
+          // V operand of key block t: keys 16c + 4 half + {0..3} = unit 4c + half, and + 8 = unit 4c + half + 2; lo plane + 8
+          const unsigned char* blk = vrow + t * 4096;
+          const int ua = 4 * c + half;
+          const u32x2 vh0 = *reinterpret_cast<const u32x2*>(blk + ((ua ^ sz) << 3));
+          const u32x2 vh1 = *reinterpret_cast<const u32x2*>(blk + (((ua + 2) ^ sz) << 3));
+          const u32x2 vl0 = *reinterpret_cast<const u32x2*>(blk + (((ua + 8) ^ sz) << 3));
+          const u32x2 vl1 = *reinterpret_cast<const u32x2*>(blk + (((ua + 10) ^ sz) << 3));
           const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
           const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
           const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
@@ -308,6 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
     }
 
     // ---- [D] every wave is done with V: copy the next position's V
+    FD_STAMP(7);
+    ++slot;
     barrier_keep_vm();
     issue_v(nxt);
 
@@ -329,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
     done = is_last(cur);
     advance(nxt);
   }
+#undef FD_STAMP
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
@@ -347,6 +364,8 @@ static void launch(const AttnImgArgs& p, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipDeviceProp_t prop;
     n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     attr_set[dev] = true;
@@ -354,7 +373,8 @@ static void launch(const AttnImgArgs& p, hipStream_t s) {
   const int nitems = p.B * p.H * p.NKT;
   int grid = 2 * n_cu[dev];  // two 4-wave workgroups per CU (registers: 2 waves per SIMD)
   if (grid > nitems) grid = nitems;
-  if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, true>), dim3(grid), dim3(256), smem, s, p);
+  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, false, true>), dim3(grid), dim3(256), smem, s, p);
+  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, true>), dim3(grid), dim3(256), smem, s, p);
   else hipLaunchKernelGGL((attn_img_kernel<T, REL, false>), dim3(grid), dim3(256), smem, s, p);
 }
 

@@ -139,7 +139,7 @@ struct GemmImgArgs {
   unsigned char* out;          // image [rows128][N/32]   EPI_IMG_GELU / EPI_IMG_LN
   unsigned char* qbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK
   unsigned char* kbuf;         // [B][H][LTOT][144 B]     EPI_IMG_QK
-  unsigned char* vbuf;         // [B][H][NKT][32][4 LPK + 8 B]   EPI_IMG_VT
+  unsigned char* vbuf;         // [B][H][LTOT / 32][32 d][128 B]  EPI_IMG_VT (V transposed, swizzled: gemm_img.hip)
   unsigned char* trash;        // >= 256 B scratch line for the stores of padding rows
   const int2* rowinfo;
   const int* dims;
@@ -150,6 +150,7 @@ struct GemmImgArgs {
   float resid_inv;             // 1 / scale of the residual image
   float eps;                   // LayerNorm eps
   float q_scale, k_scale, v_scale;
+  unsigned long long* stamps;  // null, or [5 epilogues][8 waves][64 slots][6] cycle stamps of workgroup 0 (debug)
 };
 // max_rows bounds the grid (B * ceil8(L) of the workspace); the kernel reads the actual count from p.dims.
 void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s);
@@ -167,6 +168,7 @@ struct AttnImgArgs {
   int B, H, LTOT, NKT, maxpos;
   float q_scale, k_scale, v_scale, ctx_scale;
   float r_scale;               // k_scale / scale of the distance table
+  unsigned long long* stamps;  // null, or [4 waves][64 slots][8] cycle stamps of workgroup 0 (debug)
 };
 bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s);
 

@@ -3,7 +3,7 @@
 //   C[M,N] = A[M,K] * W[N,K]^T + bias[N]   then one of four epilogues
 //     EPI_QK    q | k of HF BertSelfAttention (transformers 4.11.3, called from foldingdiff/modelling.py:473-480)
 //               scattered per (sequence, head) in the layouts the attention kernel DMA-copies into LDS
-//     EPI_VT    v, written transposed per (sequence, head, key tile): [d][hi keys | lo keys]
+//     EPI_VT    v, written transposed per (sequence, head, 32-key block): [d][hi keys | lo keys], swizzled
 //     EPI_GELU  BertIntermediate.dense / AnglesPredictor.dense1 + exact-erf GELU (modelling.py:195-196, :203-205)
 //     EPI_LN    BertSelfOutput / BertOutput: LayerNorm(dense(x) + residual)
 //
@@ -31,6 +31,9 @@
 
 namespace fdmi {
 namespace gi {
+
+struct StreamNo { static constexpr bool value = false; };
+struct StreamYes { static constexpr bool value = true; };
 
 constexpr int BM = 128, BN = 384, NTHR = 512;
 constexpr int W_STAGE = BN * 128, A_STAGE = BM * 128;           // bytes per k-tile stage
@@ -62,7 +65,12 @@ __device__ __forceinline__ float gelu_erf(float x) {  // HF "gelu": 0.5 x (1 + e
   return __builtin_fmaf(h, erf_rational(x * 0.70710678118654752440f), h);
 }
 
-template <int EPI, bool SWAP>
+// PROF: workgroup 0 records s_memtime stamps of its waves (debug instrumentation, FDMI_STAMPS=1):
+//   stamps[EPI][wave][slot][6] = {loop top, after the vmcnt wait, after the barrier, after the DMA issue, after compute,
+//   after the epilogue (last k-tile of a tile only)}
+// DBG (ablation builds, FDMI_GEMM_DBG, wrong results by design): 1 = no DMA pieces inside the k-loop, 2 = no MFMAs,
+// 3 = no fragment reads + no MFMAs (DMA only)
+template <int EPI, bool SWAP, bool PROF, int DBG = 0>
 __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -104,15 +112,57 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   int iw_n0, ia_m0;  // tile origin of the issue cursors (recomputed only when the cursor enters a new tile)
   tile_mn(0, ia_m0, iw_n0);
-  auto issue_w = [&]() {
-    const int n0 = iw_n0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(p.W) + (size_t)n0 * rb, 0, BN * rb, 0x00020000);
-    lds_ptr_t dst = (lds_ptr_t)(smem) + iw_slot * W_STAGE + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma16(rs, dst + i * 8192, voff, iw_kt * 128 + i * 64 * rb);
+  // The 8 pieces of a wave (6 W + 2 A) are issued BETWEEN the MFMAs of compute(): all 64 pieces of a k-tile go through
+  // the CU's one vector-memory pipe (64 B/clk: >= 1024 cycles per k-tile), and a wave stalls on issue while that
+  // pipe's queue is full -- back to back after the barrier that was ~1000 cycles per k-tile with the matrix pipe idle
+  // (measured with the PROF stamps), spread out it hides behind the 2304 MFMA cycles.
+  __amdgpu_buffer_rsrc_t rs_w, rs_a;
+  lds_ptr_t dst_w, dst_a;
+  int so_w, so_a;
+  // branch-free (selects only), so that it sits in the same basic block as the MFMAs and the scheduler can sink the
+  // scalar work between them instead of running it on the critical path right after the barrier
+  auto begin_issue = [&]() {
+    rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.W) + (size_t)iw_n0 * rb, 0, BN * rb, 0x00020000);
+    dst_w = (lds_ptr_t)(smem) + iw_slot * W_STAGE + wid * 1024;
+    so_w = iw_kt * 128;
     iw_slot ^= 1;
-    if (iw_ti * nk + iw_kt + 1 < G) {  // past the end: re-issue the last position (lands in a free slot, never read)
+    {
+      const bool more = iw_ti * nk + iw_kt + 1 < G;  // past the end: re-issue the last position (free slot, never read)
+      const bool wrap = more && iw_kt + 1 == nk;
+      const int nti = wrap ? iw_ti + 1 : iw_ti;
+      int mm, nn;
+      tile_mn(nti, mm, nn);
+      iw_kt = wrap ? 0 : (more ? iw_kt + 1 : iw_kt);
+      iw_ti = nti;
+      iw_n0 = nn;
+    }
+    rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.A) + (size_t)ia_m0 * rb, 0, BM * rb, 0x00020000);
+    dst_a = (lds_ptr_t)(smem) + OFF_A + ia_slot * A_STAGE + wid * 1024;
+    so_a = ia_kt * 128;
+    ia_slot = ia_slot == NAS - 1 ? 0 : ia_slot + 1;
+    {
+      const bool more = ia_ti * nk + ia_kt + 1 < G;
+      const bool wrap = more && ia_kt + 1 == nk;
+      const int nti = wrap ? ia_ti + 1 : ia_ti;
+      int mm, nn;
+      tile_mn(nti, mm, nn);
+      ia_kt = wrap ? 0 : (more ? ia_kt + 1 : ia_kt);
+      ia_ti = nti;
+      ia_m0 = mm;
+    }
+  };
+  auto piece = [&](int i) {  // i = 0..5: W pieces, 6..7: A pieces (this order is what the vmcnt bookkeeping assumes)
+    if constexpr (DBG == 1) return;
+    if (i < 6) dma16(rs_w, dst_w + i * 8192, voff, so_w + i * 64 * rb);
+    else dma16(rs_a, dst_a + (i - 6) * 8192, voff, so_a + (i - 6) * 64 * rb);
+  };
+  auto issue_w = [&]() {  // prologue only
+    rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.W) + (size_t)iw_n0 * rb, 0, BN * rb, 0x00020000);
+    dst_w = (lds_ptr_t)(smem) + iw_slot * W_STAGE + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma16(rs_w, dst_w + i * 8192, voff, iw_kt * 128 + i * 64 * rb);
+    iw_slot ^= 1;
+    if (iw_ti * nk + iw_kt + 1 < G) {
       if (++iw_kt == nk) {
         iw_kt = 0;
         ++iw_ti;
@@ -121,13 +171,11 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       }
     }
   };
-  auto issue_a = [&]() {
-    const int m0 = ia_m0;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(p.A) + (size_t)m0 * rb, 0, BM * rb, 0x00020000);
-    lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + ia_slot * A_STAGE + wid * 1024;
+  auto issue_a = [&]() {  // prologue only
+    rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.A) + (size_t)ia_m0 * rb, 0, BM * rb, 0x00020000);
+    dst_a = (lds_ptr_t)(smem) + OFF_A + ia_slot * A_STAGE + wid * 1024;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(rs, dst + i * 8192, voff, ia_kt * 128 + i * 64 * rb);
+    for (int i = 0; i < 2; ++i) dma16(rs_a, dst_a + i * 8192, voff, ia_kt * 128 + i * 64 * rb);
     ia_slot = ia_slot == NAS - 1 ? 0 : ia_slot + 1;
     if (ia_ti * nk + ia_kt + 1 < G) {
       if (++ia_kt == nk) {
@@ -163,41 +211,61 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   zero_acc();
 
-  auto compute = [&](int wslot, int aslot) {
+  // MFMA order: term by term over the six tiles (consecutive MFMAs never share an accumulator).  One DMA piece goes
+  // behind every fourth / fifth MFMA: 4 pieces per k16 step.
+  auto compute = [&](int wslot, int aslot, auto swap_form) {
+    constexpr bool SW = decltype(swap_form)::value;
+    auto mm = [&](const f16x8& wf, const f16x8& af, f32x16& c) {
+      if constexpr (DBG >= 2) {
+        if constexpr (DBG == 2) asm volatile("" ::"v"(wf), "v"(af));
+        return;
+      }
+      c = SW ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, c, 0, 0, 0);
+    };
     const unsigned char* wb = smem + wslot * W_STAGE;
     const unsigned char* ab = smem + aslot * A_STAGE;
+    f16x8 wh[2][3], wl[2][3], ah[2][2], al[2][2];  // [k16 step][tile]
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      f16x8 wh[3], wl[3], ah[2], al[2];
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
-        wh[jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][0] + jn * 4096);
-        wl[jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][1] + jn * 4096);
+        wh[c][jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][0] + jn * 4096);
+        wl[c][jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][1] + jn * 4096);
       }
 #pragma unroll
       for (int im = 0; im < 2; ++im) {
-        ah[im] = *reinterpret_cast<const f16x8*>(ab + ard[c][0] + im * 4096);
-        al[im] = *reinterpret_cast<const f16x8*>(ab + ard[c][1] + im * 4096);
+        ah[c][im] = *reinterpret_cast<const f16x8*>(ab + ard[c][0] + im * 4096);
+        al[c][im] = *reinterpret_cast<const f16x8*>(ab + ard[c][1] + im * 4096);
       }
-      // term by term over the six tiles: consecutive MFMAs never share an accumulator
+    }
+    begin_issue();
 #pragma unroll
-      for (int jn = 0; jn < 3; ++jn)
+    for (int c = 0; c < 2; ++c) {
+      // hi * hi
+      mm(wh[c][0], ah[c][0], acc[0][0]); mm(wh[c][0], ah[c][1], acc[0][1]); mm(wh[c][1], ah[c][0], acc[1][0]); mm(wh[c][1], ah[c][1], acc[1][1]);
+      piece(4 * c + 0);
+      mm(wh[c][2], ah[c][0], acc[2][0]); mm(wh[c][2], ah[c][1], acc[2][1]);
+      // hi * lo
+      mm(wh[c][0], al[c][0], acc[0][0]); mm(wh[c][0], al[c][1], acc[0][1]);
+      piece(4 * c + 1);
+      mm(wh[c][1], al[c][0], acc[1][0]); mm(wh[c][1], al[c][1], acc[1][1]); mm(wh[c][2], al[c][0], acc[2][0]); mm(wh[c][2], al[c][1], acc[2][1]);
+      piece(4 * c + 2);
+      // lo * hi
+      mm(wl[c][0], ah[c][0], acc[0][0]); mm(wl[c][0], ah[c][1], acc[0][1]); mm(wl[c][1], ah[c][0], acc[1][0]); mm(wl[c][1], ah[c][1], acc[1][1]);
+      piece(4 * c + 3);
+      mm(wl[c][2], ah[c][0], acc[2][0]); mm(wl[c][2], ah[c][1], acc[2][1]);
+    }
+    // Pin the schedule: all twenty fragment reads of the k-tile first (their latency is then paid once, under the other
+    // wave's MFMAs, instead of once per k16 step), then {4 MFMA, 1 VMEM} x 4 + 2 MFMA per k16 step.
+    __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
 #pragma unroll
-        for (int im = 0; im < 2; ++im)
-          acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], ah[im], acc[jn][im], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], wh[jn], acc[jn][im], 0, 0, 0);
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int jn = 0; jn < 3; ++jn)
-#pragma unroll
-        for (int im = 0; im < 2; ++im)
-          acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[jn], al[im], acc[jn][im], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[im], wh[jn], acc[jn][im], 0, 0, 0);
-#pragma unroll
-      for (int jn = 0; jn < 3; ++jn)
-#pragma unroll
-        for (int im = 0; im < 2; ++im)
-          acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[jn], ah[im], acc[jn][im], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], wl[jn], acc[jn][im], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
   };
 
@@ -275,7 +343,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       // normal MFMA form: lane = column (d = l31 of head cb), register r = 4q + e <-> token row 8q + 4 half + e of the
       // 32-row MFMA tile.  After the exchange the lower lane holds token octets 0, 1 and the upper lane 2, 3 of the
       // tile; sequences start at multiples of 8 rows, so an octet never straddles two sequences.
-      const int H = p.H, LP = p.LPK, vrow = 4 * LP + 8;
+      // V^T block layout: [b][h][key block l/32][d][128 B = sixteen 8-byte units: hi keys 4u..4u+3 (u < 8) | lo],
+      // unit u stored at position u ^ ((d >> 1) & 15) (conflict-free 8-byte LDS fetches in the attention kernel
+      // after a linear LDS-DMA copy); an octet = one aligned 16-byte pair of units, halves swapped when the
+      // swizzle is odd -- so every store is an aligned 16-byte piece of a 128-byte line, as in the q / k epilogue.
+      const int H = p.H, nkb = p.LTOT >> 5;
+      const int sz = (l31 >> 1) & 15;
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn;
@@ -294,14 +367,19 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             const int2 ri = p.rowinfo[m0 + wm * 64 + im * 32 + 16 * half + 8 * u];
             const bool ok = ri.x >= 0;
             const int lpos = ok ? ri.y : 0;
-            const int kt = lpos / LP, kl = lpos - kt * LP;
-            unsigned char* row = ok ? p.vbuf + ((((size_t)ri.x * H + cb) * p.NKT + kt) * 32 + l31) * vrow + 2 * kl : p.trash;
-            *reinterpret_cast<u32x4*>(row) = hh[u];
-            *reinterpret_cast<u32x4*>(row + (ok ? 2 * LP : 64)) = ll[u];
+            const int kb = lpos >> 5, oc = (lpos & 31) >> 3;
+            unsigned char* row = ok ? p.vbuf + ((((size_t)ri.x * H + cb) * nkb + kb) * 32 + l31) * 128 : p.trash;
+            u32x4 vh = hh[u], vl = ll[u];
+            if (sz & 1) {
+              vh = u32x4{vh[2], vh[3], vh[0], vh[1]};
+              vl = u32x4{vl[2], vl[3], vl[0], vl[1]};
+            }
+            *reinterpret_cast<u32x4*>(row + ((oc ^ (sz >> 1)) << 4)) = vh;
+            *reinterpret_cast<u32x4*>(row + (((4 + oc) ^ (sz >> 1)) << 4)) = vl;
           }
         }
       }
-    } else {  // EPI_IMG_LN
+    } else if constexpr (EPI == EPI_IMG_LN) {
       const int N = p.N, nb = N >> 5;
       const float* par = reinterpret_cast<const float*>(smem + OFF_PAR);
       float* red = reinterpret_cast<float*>(smem + OFF_RED);
@@ -404,25 +482,42 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   issue_a();
   int cw = 0, ca = 0;  // slots of the position being computed
   int nv_prev = -1;    // column blocks stored by the previous tile's epilogue (-1: none yet)
+  const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
+  unsigned long long* st = PROF ? p.stamps + ((size_t)EPI * 8 + wid) * 64 * 6 : nullptr;
+  int slot = 0;
+#define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 6 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
   for (int ti = 0; ti < cnt; ++ti) {
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt == 0 && nv_prev > 0) {
+      FD_STAMP(0);
+      if constexpr (DBG == 1) {
+        // nothing in flight
+      } else if (kt == 0 && nv_prev > 0) {
         if (nv_prev == 3) FD_WAIT_VM(2 + 24);
         else if (nv_prev == 2) FD_WAIT_VM(2 + 16);
         else FD_WAIT_VM(2 + 8);
       } else {
         FD_WAIT_VM(2);
       }
+      FD_STAMP(1);
       barrier_keep_vm();  // (also publishes the EPI_LN parameter image before the first epilogue)
-      issue_w();
-      issue_a();
-      compute(cw, ca);
+      FD_STAMP(2);
+      FD_STAMP(3);
+      if constexpr (SWAP) {
+        compute(cw, ca, StreamYes{});
+      } else {
+        compute(cw, ca, StreamNo{});
+      }
+      FD_STAMP(4);
       cw ^= 1;
       ca = ca == NAS - 1 ? 0 : ca + 1;
+      if (kt + 1 < nk) ++slot;
     }
     nv_prev = epilogue(ti);
+    FD_STAMP(5);
+    ++slot;
     zero_acc();
   }
+#undef FD_STAMP
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
@@ -443,7 +538,9 @@ static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set[dev] = true;
   }
@@ -451,7 +548,21 @@ static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
   int grid = n_cu_of_current_device() / 8 * 8;
   if (grid > ntiles_max) grid = (ntiles_max + 7) / 8 * 8;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP>), dim3(grid), dim3(NTHR), SMEM, s, p);
+  static const int dbg = [] { const char* e = getenv("FDMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
+  if (dbg >= 1 && dbg <= 3) {
+    if constexpr (EPI == EPI_IMG_QK) {  // ablations are built for the QK projection only
+      const void* f = dbg == 1 ? reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 1>)
+                    : dbg == 2 ? reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 2>)
+                               : reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 3>);
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      if (dbg == 1) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 1>), dim3(grid), dim3(NTHR), SMEM, s, p);
+      else if (dbg == 2) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 2>), dim3(grid), dim3(NTHR), SMEM, s, p);
+      else hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 3>), dim3(grid), dim3(NTHR), SMEM, s, p);
+      return;
+    }
+  }
+  if (p.stamps) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, true>), dim3(grid), dim3(NTHR), SMEM, s, p);
+  else hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false>), dim3(grid), dim3(NTHR), SMEM, s, p);
 }
 
 }  // namespace gi

@@ -335,7 +335,7 @@ __global__ void img_to_f32_kernel(const unsigned char* __restrict__ src, float* 
   }
 }
 
-// debug: q / k rows ([BH][LTOT][rowbytes], hi d0-31 | lo d0-31) or v^T ([BH][NKT][32][4 LP + 8]) -> fp32 [BH][LTOT][32]
+// debug: q / k rows ([BH][LTOT][rowbytes], hi d0-31 | lo d0-31) or v^T blocks -> fp32 [BH][LTOT][32]
 __global__ void qkv_unpack_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long BH, int LTOT,
                                   int LP, int rowbytes, int is_vt, float inv_s) {
   const long long n = BH * LTOT * 32;
@@ -345,11 +345,11 @@ __global__ void qkv_unpack_kernel(const unsigned char* __restrict__ src, float* 
     const long long bh = row / LTOT;
     const int l = (int)(row - bh * LTOT);
     const _Float16 *hp, *lp;
-    if (is_vt) {
-      const int kt = l / LP, kl = l - kt * LP, vrow = 4 * LP + 8;
-      const unsigned char* r = src + (((bh * (LTOT / LP) + kt) * 32) + dd) * (size_t)vrow;
-      hp = reinterpret_cast<const _Float16*>(r) + kl;
-      lp = reinterpret_cast<const _Float16*>(r + 2 * LP) + kl;
+    if (is_vt) {  // [bh][l / 32][d][128 B], 8-byte unit u at position u ^ ((d >> 1) & 15)
+      const int kb = l >> 5, kl = l & 31, sz = (dd >> 1) & 15;
+      const unsigned char* r = src + (((bh * (LTOT >> 5) + kb) * 32) + dd) * (size_t)128;
+      hp = reinterpret_cast<const _Float16*>(r + (((kl >> 2) ^ sz) << 3)) + (kl & 3);
+      lp = reinterpret_cast<const _Float16*>(r + (((8 + (kl >> 2)) ^ sz) << 3)) + (kl & 3);
     } else {
       const unsigned char* r = src + row * (size_t)rowbytes;
       hp = reinterpret_cast<const _Float16*>(r) + dd;
