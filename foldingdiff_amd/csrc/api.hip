@@ -49,7 +49,7 @@ struct SplitW {
 };
 
 struct LayerDev {
-  SplitW wqkv_s, wo_s, wi_s, wd_s, demb_s;
+  SplitW demb_s;  // distance table as an fp16 hi|lo row image (row-image attention)
   // row-image path: weight images padded to 384 rows, and the (static, power-of-two) scales of this layer's
   // activation images -- derived from norm bounds of the weights at fd_finalize, so nothing can overflow fp16
   SplitW wqk_i, wv_i, wo_i, wi_i, wd_i;
@@ -118,7 +118,7 @@ struct fd_model {
   float *w_in = nullptr, *b_in = nullptr, *pos_emb = nullptr, *emb_g = nullptr, *emb_b = nullptr;
   std::vector<LayerDev> layers;
   float *hd_w1 = nullptr, *hd_b1 = nullptr, *hd_g = nullptr, *hd_b = nullptr, *hd_w2 = nullptr, *hd_b2 = nullptr;
-  SplitW hd_w1_s, hd_w1_i;
+  SplitW hd_w1_i;
   float s_hfinal = 1.f, s_hg = 1.f;  // row-image scales: last hidden state, head activation
   bool img = false;                  // FD_PREC_F16X3 runs on the row-image kernels
   float *coef = nullptr, *time_table = nullptr;
@@ -209,11 +209,6 @@ void free_weights(fd_model* m) {
 // and ||y||_2 <= max|gamma| sqrt(d) + ||beta||_2; a dense output |y W_j + b_j| <= ||y||_2 ||W_j||_2 + |b_j|; GELU and the
 // softmax-weighted average of V do not grow their argument.  Nothing overflows for ANY weights (trained outliers
 // included); elements far below the bound merely lose low bits of `lo` (absolute error bound * 2^-40).
-bool img_path_enabled() {
-  static const bool on = [] { const char* e = getenv("FDMI_IMG"); return !e || atoi(e) != 0; }();
-  return on;
-}
-
 struct Bound {
   float linf, l2;
 };
@@ -465,15 +460,10 @@ int harvest(fd_model* m) {
 
 // One reverse-diffusion step = BertForDiffusionBase.forward (modelling.py:384-484) + the
 // p_sample update and wrap (sampling.py:62-75, :119-130), as a fixed kernel sequence.
-void gemm(fd_model* m, int epi, const float* A, const float* W, const SplitW& Ws, const float* bias, const float* resid,
-          float* C, int M, int N, int K, hipStream_t s) {
-  // 128 x 384 tiles where the shape fits; all token buffers hold whole 128-row tiles (ensure_ws), so the
-  // row count is rounded up for it
-  if (m->precision == FD_PREC_F16X3 && !resid &&
-      launch_gemm_f16x3_wide(epi, A, Ws.p, Ws.scale, bias, C, (M + 127) / 128 * 128, N, K, s))
-    return;
-  if (m->precision == FD_PREC_F16X3) launch_gemm_f16x3(epi, A, Ws.p, Ws.scale, bias, resid, C, M, N, K, s);
-  else launch_gemm_f32(epi, A, W, bias, resid, C, M, N, K, s);
+void gemm(fd_model* m, int epi, const float* A, const float* W, const float* bias, const float* resid, float* C, int M,
+          int N, int K, hipStream_t s) {
+  (void)m;
+  launch_gemm_f32(epi, A, W, bias, resid, C, M, N, K, s);
 }
 
 int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode);
@@ -483,23 +473,18 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
   const fd_config& c = m->cfg;
   Workspace& w = m->ws;
   const int B = w.B, L = w.L, M = B * L, d = c.d_model, ff = c.d_ff, F = c.n_features;
-  const bool split = m->precision == FD_PREC_F16X3;
-  const bool fuse_ln = m->fuse_ln < 0 ? split : m->fuse_ln != 0;  // auto: on for fp16x3 (measured +8 %), off for fp32
-  const int Mp = (M + 127) / 128 * 128;                           // fused kernels run on whole (padded) tiles
+  const bool fuse_ln = m->fuse_ln > 0;  // fp32 path: the LN-fused fp32 GEMM is slower than GEMM + LayerNorm, off unless asked for
   PROF(KC_EMBED, launch_embed(w.x, m->w_in, m->b_in, m->pos_emb, m->emb_g, m->emb_b, c.ln_eps, m->time_table, w.t_dev,
                               w.h, B, L, F, d, s));
   for (int li = 0; li < c.n_layers; ++li) {
     const LayerDev& lw = m->layers[li];
-    PROF(KC_GEMM_QKV, gemm(m, EPI_BIAS, w.h, lw.wqkv, lw.wqkv_s, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
+    PROF(KC_GEMM_QKV, gemm(m, EPI_BIAS, w.h, lw.wqkv, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
     bool ok = true;
-    PROF(KC_ATTN, ok = (m->precision == FD_PREC_F16X3 && m->attn_f16)
-                        ? launch_attention_f16x3(w.qkv, lw.demb_s.p, lw.demb_s.scale, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s)
-                        : launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
+    PROF(KC_ATTN, ok = launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
     if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by the fp32 kernel (max 128)", L);
     bool fused = false;
     if (fuse_ln)
-      PROF(KC_GEMM_OUT, fused = split ? launch_gemm_f16x3_ln(w.ctx, lw.wo_s.p, lw.wo_s.scale, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, Mp, d, d, s)
-                                       : launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
+      PROF(KC_GEMM_OUT, fused = launch_gemm_f32_ln(w.ctx, lw.wo, lw.bo, w.h, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, d, s));
     if (!fused) {
       if (fuse_ln && mode.profile) {  // the attempted launch recorded an empty bracket; drop it
         PendingEvent p = m->pending.back();
@@ -507,14 +492,13 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
         m->event_pool.push_back(p.e0);
         m->event_pool.push_back(p.e1);
       }
-      PROF(KC_GEMM_OUT, gemm(m, EPI_BIAS_RESID, w.ctx, lw.wo, lw.wo_s, lw.bo, w.h, w.tmp, M, d, d, s));
+      PROF(KC_GEMM_OUT, gemm(m, EPI_BIAS_RESID, w.ctx, lw.wo, lw.bo, w.h, w.tmp, M, d, d, s));
       PROF(KC_LN1, launch_layernorm(w.tmp, lw.ln1g, lw.ln1b, c.ln_eps, w.a, M, d, s));
     }
-    PROF(KC_GEMM_UP, gemm(m, EPI_BIAS_GELU, w.a, lw.wi, lw.wi_s, lw.bi, nullptr, w.g, M, ff, d, s));
+    PROF(KC_GEMM_UP, gemm(m, EPI_BIAS_GELU, w.a, lw.wi, lw.bi, nullptr, w.g, M, ff, d, s));
     fused = false;
     if (fuse_ln)
-      PROF(KC_GEMM_DOWN, fused = split ? launch_gemm_f16x3_ln(w.g, lw.wd_s.p, lw.wd_s.scale, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, Mp, d, ff, s)
-                                        : launch_gemm_f32_ln(w.g, lw.wd, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s));
+      PROF(KC_GEMM_DOWN, fused = launch_gemm_f32_ln(w.g, lw.wd, lw.bd, w.a, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, ff, s));
     if (!fused) {
       if (fuse_ln && mode.profile) {
         PendingEvent p = m->pending.back();
@@ -522,14 +506,14 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
         m->event_pool.push_back(p.e0);
         m->event_pool.push_back(p.e1);
       }
-      PROF(KC_GEMM_DOWN, gemm(m, EPI_BIAS_RESID, w.g, lw.wd, lw.wd_s, lw.bd, w.a, w.tmp, M, d, ff, s));
+      PROF(KC_GEMM_DOWN, gemm(m, EPI_BIAS_RESID, w.g, lw.wd, lw.bd, w.a, w.tmp, M, d, ff, s));
       PROF(KC_LN2, launch_layernorm(w.tmp, lw.ln2g, lw.ln2b, c.ln_eps, w.h, M, d, s));
     }
   }
   UpdateArgs u;
   memset(&u, 0, sizeof u);
   if (c.decoder == FD_DEC_MLP) {
-    PROF(KC_GEMM_HEAD, gemm(m, EPI_BIAS_GELU, w.h, m->hd_w1, m->hd_w1_s, m->hd_b1, nullptr, w.g, M, d, d, s));
+    PROF(KC_GEMM_HEAD, gemm(m, EPI_BIAS_GELU, w.h, m->hd_w1, m->hd_b1, nullptr, w.g, M, d, d, s));
     u.g = w.g;
     u.gamma = m->hd_g;
     u.beta = m->hd_b;
@@ -731,7 +715,7 @@ int check_shape(fd_model* m, int B, int L, int t) {
     return fail(FD_E_INVALID, "L=%d exceeds max_position_embeddings=%d", L, m->cfg.max_pos);
   if (m->cfg.pos_type == FD_POS_ABSOLUTE && L > m->cfg.max_pos)
     return fail(FD_E_INVALID, "L=%d exceeds max_position_embeddings=%d", L, m->cfg.max_pos);
-  if (L > 128 && !(m->precision == FD_PREC_F16X3 && m->attn_f16))
+  if (L > 128 && !m->img)
     return fail(FD_E_UNSUPPORTED, "L=%d: the exact-fp32 attention kernel handles L <= 128; use FD_PREC_F16X3", L);
   return FD_OK;
 }
@@ -962,7 +946,9 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
   const size_t d = c.d_model, F = c.n_features, ff = c.d_ff;
   // FD_PREC_F16X3 runs on the row-image kernels (LayerNorm rows must fit one 384-column workgroup tile);
   // FDMI_IMG=0 keeps the previous register-staged split kernels (A/B knob)
-  const bool img = precision == FD_PREC_F16X3 && d <= 384 && img_path_enabled();
+  if (precision == FD_PREC_F16X3 && d > 384)
+    return fail(FD_E_UNSUPPORTED, "FD_PREC_F16X3 fuses LayerNorm rows into one 384-column workgroup tile: d_model=%d > 384 needs FD_PREC_F32", (int)d);
+  const bool img = precision == FD_PREC_F16X3;
   m->img = img;
 #define NEED(var, nm)                         \
   const HostTensor* var = need(m, nm);        \
@@ -1000,8 +986,6 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     for (const HostTensor* t : {bq, bk, bv}) bqkv.insert(bqkv.end(), t->data.begin(), t->data.end());
     if (int rc = upload(m, &lw.wqkv, wqkv.data(), wqkv.size())) return rc;
     if (int rc = upload(m, &lw.bqkv, bqkv.data(), bqkv.size())) return rc;
-    if (precision == FD_PREC_F16X3 && !img)
-      if (int rc = upload_split(m, &lw.wqkv_s, wqkv.data(), 3 * (int)d, (int)d)) return rc;
     if (img) {
       if (int rc = upload_split(m, &lw.wqk_i, wqkv.data(), 2 * (int)d, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wv_i, wqkv.data() + 2 * d * d, (int)d, (int)d, 384)) return rc;
@@ -1031,11 +1015,6 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     NEED(b2, p + "output.LayerNorm.bias");
     UP(lw.wo, wo); UP(lw.bo, bo); UP(lw.ln1g, g1); UP(lw.ln1b, b1);
     UP(lw.wi, wi); UP(lw.bi, bi); UP(lw.wd, wd); UP(lw.bd, bd); UP(lw.ln2g, g2); UP(lw.ln2b, b2);
-    if (precision == FD_PREC_F16X3 && !img) {
-      if (int rc = upload_split(m, &lw.wo_s, wo->data.data(), (int)d, (int)d)) return rc;
-      if (int rc = upload_split(m, &lw.wi_s, wi->data.data(), (int)ff, (int)d)) return rc;
-      if (int rc = upload_split(m, &lw.wd_s, wd->data.data(), (int)d, (int)ff)) return rc;
-    }
     if (img) {
       if (int rc = upload_split(m, &lw.wo_i, wo->data.data(), (int)d, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wi_i, wi->data.data(), (int)ff, (int)d, 384)) return rc;
@@ -1055,8 +1034,6 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     NEED(w2, "token_decoder.dense2.weight");
     NEED(b2, "token_decoder.dense2.bias");
     UP(m->hd_w1, w1); UP(m->hd_b1, b1); UP(m->hd_g, g); UP(m->hd_b, b); UP(m->hd_w2, w2); UP(m->hd_b2, b2);
-    if (precision == FD_PREC_F16X3 && !img)
-      if (int rc = upload_split(m, &m->hd_w1_s, w1->data.data(), (int)d, (int)d)) return rc;
     if (img) {
       if (int rc = upload_split(m, &m->hd_w1_i, w1->data.data(), (int)d, (int)d, 384)) return rc;
       m->s_hg = scale_for(dense_bound(w1->data.data(), b1->data.data(), 0, (int)d, (int)d, hb.l2));
@@ -1207,6 +1184,11 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
 
 int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
               uint64_t seed, float* out, int full_history) {
+  return fd_sample_ex(m, x_init, lens, B, L, t_start, noise, seed, 0, out, full_history);
+}
+
+int fd_sample_ex(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
+                 uint64_t seed, int64_t seq_offset, float* out, int full_history) {
   if (int rc = check_shape(m, B, L, t_start)) return rc;
   if (!x_init || !lens || !out) return fail(FD_E_INVALID, "null argument");
   if (full_history < 0) return fail(FD_E_INVALID, "full_history = %d", full_history);
@@ -1240,7 +1222,7 @@ int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int 
     TRY_CLEAN(hipMalloc((void**)&d_noise, nsteps * n * 4));
     TRY_CLEAN(hipMemcpy(d_noise, noise, nsteps * n * 4, hipMemcpyHostToDevice));
   }
-  rc = fd_sample_dev(m, d_x, d_lens, B, L, t_start, d_noise, seed, 0, d_out, full_history, nullptr);
+  rc = fd_sample_dev(m, d_x, d_lens, B, L, t_start, d_noise, seed, seq_offset, d_out, full_history, nullptr);
   if (rc) {
     cleanup();
     return rc;
@@ -1306,7 +1288,7 @@ int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, con
   if (epilogue < EPI_BIAS || epilogue > EPI_BIAS_RESID || (epilogue == EPI_BIAS_RESID && !resid))
     return fail(FD_E_INVALID, "bad epilogue");
   HIP_TRY(hipSetDevice(device_id));
-  if (precision == FD_PREC_F16X3 && img_path_enabled()) {
+  if (precision == FD_PREC_F16X3) {
     if (epilogue == EPI_BIAS_RESID)
       return fail(FD_E_UNSUPPORTED, "the row-image path has no unfused residual epilogue (LayerNorm is always fused): use fd_test_gemm_ln");
     return img_gemm_hook(epilogue == EPI_BIAS_GELU ? EPI_IMG_GELU : EPI_IMG_BIAS, A, W, bias, nullptr, nullptr, nullptr, 0.f, C, M, N, K);
@@ -1338,13 +1320,7 @@ int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, con
     T_TRY(hipMalloc((void**)&dr, (size_t)M * N * 4));
     T_TRY(hipMemcpy(dr, resid, (size_t)M * N * 4, hipMemcpyHostToDevice));
   }
-  if (precision == FD_PREC_F16X3) {
-    std::vector<uint16_t> img;
-    pack_split_weight(W, N, K, &img, &wscale);
-    T_TRY(hipMalloc(&dWp, img.size() * 2));
-    T_TRY(hipMemcpy(dWp, img.data(), img.size() * 2, hipMemcpyHostToDevice));
-    launch_gemm_f16x3(epilogue, dA, dWp, wscale, db, dr, dC, M, N, K, nullptr);
-  } else if (precision == FD_PREC_F32) {
+  if (precision == FD_PREC_F32) {
     launch_gemm_f32(epilogue, dA, dW, db, dr, dC, M, N, K, nullptr);
   } else {
     cleanup();
@@ -1365,7 +1341,7 @@ int fd_test_gemm_ln(int device_id, int precision, int use_fused, const float* A,
     return fail(FD_E_INVALID, "bad argument");
   if (precision != FD_PREC_F32 && precision != FD_PREC_F16X3) return fail(FD_E_INVALID, "precision %d", precision);
   HIP_TRY(hipSetDevice(device_id));
-  if (precision == FD_PREC_F16X3 && img_path_enabled()) {
+  if (precision == FD_PREC_F16X3) {
     if (!use_fused) return fail(FD_E_UNSUPPORTED, "the row-image path always fuses the LayerNorm into the GEMM");
     return img_gemm_hook(EPI_IMG_LN, A, W, bias, resid, gamma, beta, eps, C, M, N, K);
   }
@@ -1396,24 +1372,14 @@ int fd_test_gemm_ln(int device_id, int precision, int use_fused, const float* A,
   T_TRY(up(beta, (size_t)N * 4, (void**)&dbt));
   T_TRY(up(nullptr, (size_t)M * N * 4, (void**)&dT));
   T_TRY(up(nullptr, (size_t)M * N * 4, (void**)&dC));
-  void* dWp = nullptr;
-  float wscale = 1.f;
-  if (precision == FD_PREC_F16X3) {
-    std::vector<uint16_t> img;
-    pack_split_weight(W, N, K, &img, &wscale);
-    T_TRY(up(img.data(), img.size() * 2, &dWp));
-  }
   if (use_fused) {
-    const bool ok = precision == FD_PREC_F16X3
-                        ? launch_gemm_f16x3_ln(dA, dWp, wscale, db, dr, dg, dbt, eps, dC, M, N, K, nullptr)
-                        : launch_gemm_f32_ln(dA, dW, db, dr, dg, dbt, eps, dC, M, N, K, nullptr);
+    const bool ok = launch_gemm_f32_ln(dA, dW, db, dr, dg, dbt, eps, dC, M, N, K, nullptr);
     if (!ok) {
       cleanup();
       return fail(FD_E_UNSUPPORTED, "no LN-fused GEMM for N=%d K=%d in this precision", N, K);
     }
   } else {
-    if (precision == FD_PREC_F16X3) launch_gemm_f16x3(EPI_BIAS_RESID, dA, dWp, wscale, db, dr, dT, M, N, K, nullptr);
-    else launch_gemm_f32(EPI_BIAS_RESID, dA, dW, db, dr, dT, M, N, K, nullptr);
+    launch_gemm_f32(EPI_BIAS_RESID, dA, dW, db, dr, dT, M, N, K, nullptr);
     launch_layernorm(dT, dg, dbt, eps, dC, M, N, nullptr);
   }
   T_TRY(hipGetLastError());
@@ -1426,47 +1392,59 @@ int fd_test_gemm_ln(int device_id, int precision, int use_fused, const float* A,
 
 int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int reps, double* ms_per_launch) {
   if (!ms_per_launch || M < 1 || N < 1 || K < 32 || K % 32 || reps < 1) return fail(FD_E_INVALID, "bad argument");
+  if (precision == FD_PREC_F16X3 && N % 32) return fail(FD_E_UNSUPPORTED, "row-image GEMM: N=%d must be a multiple of 32", N);
   HIP_TRY(hipSetDevice(device_id));
   std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N, 0.1f);
   unsigned st = 12345u;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
   for (auto& v : hA) v = rnd();
   for (auto& v : hW) v = 0.02f * rnd();
-  float *dA = nullptr, *dW = nullptr, *db = nullptr, *dC = nullptr;
-  void* dWp = nullptr;
+  ImgHook hk;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  auto cleanup = [&]() {
-    for (void* p : {(void*)dA, (void*)dW, (void*)db, (void*)dC, dWp})
-      if (p) (void)hipFree(p);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-  };
 #define T_TRY(expr)                                                          \
   do {                                                                       \
     hipError_t e_ = (expr);                                                  \
     if (e_ != hipSuccess) {                                                  \
-      cleanup();                                                             \
+      if (e0) (void)hipEventDestroy(e0);                                     \
+      if (e1) (void)hipEventDestroy(e1);                                     \
       return fail(FD_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
     }                                                                        \
   } while (0)
-  T_TRY(hipMalloc((void**)&dA, hA.size() * 4));
-  T_TRY(hipMalloc((void**)&dW, hW.size() * 4));
-  T_TRY(hipMalloc((void**)&db, (size_t)N * 4));
-  T_TRY(hipMalloc((void**)&dC, (size_t)M * N * 4));
-  T_TRY(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
-  T_TRY(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
-  T_TRY(hipMemcpy(db, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-  float wscale = 1.f;
+  const long long rows = ((long long)M + 127) / 128 * 128;
+  float *dA, *dW, *db, *dC;
+  T_TRY(hk.up(hA.data(), hA.size() * 4, (void**)&dA));
+  T_TRY(hk.up(hW.data(), hW.size() * 4, (void**)&dW));
+  T_TRY(hk.up(hb.data(), (size_t)N * 4, (void**)&db));
+  T_TRY(hk.up(nullptr, (size_t)rows * N * 4, (void**)&dC));
+  GemmImgArgs g;
+  memset(&g, 0, sizeof g);
   if (precision == FD_PREC_F16X3) {
+    void *dAi, *dWi, *dtrash;
+    int* ddims;
     std::vector<uint16_t> img;
-    pack_split_weight(hW.data(), N, K, &img, &wscale);
-    T_TRY(hipMalloc(&dWp, img.size() * 2));
-    T_TRY(hipMemcpy(dWp, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    float wscale = 1.f;
+    pack_split_weight(hW.data(), N, K, &img, &wscale, 384);
+    T_TRY(hk.up(nullptr, (size_t)rows * K * 4, &dAi));
+    T_TRY(hk.up(img.data(), img.size() * 2, &dWi));
+    T_TRY(hk.up(nullptr, 1024, &dtrash));
+    const int hd[2] = {M, (int)rows};
+    T_TRY(hk.up(hd, sizeof hd, (void**)&ddims));
+    launch_f32_to_img(dA, dAi, rows, K, M, 8192.0f, nullptr);
+    g.A = static_cast<const unsigned char*>(dAi);
+    g.W = static_cast<const unsigned char*>(dWi);
+    g.bias = db;
+    g.out = reinterpret_cast<unsigned char*>(dC);
+    g.trash = static_cast<unsigned char*>(dtrash);
+    g.dims = ddims;
+    g.N = N;
+    g.K = K;
+    g.acc_scale = 1.0f / (8192.0f * wscale);
+    g.out_scale = 1024.0f;
   }
   T_TRY(hipEventCreate(&e0));
   T_TRY(hipEventCreate(&e1));
   auto run = [&]() {
-    if (precision == FD_PREC_F16X3) launch_gemm_f16x3(EPI_BIAS, dA, dWp, wscale, db, nullptr, dC, M, N, K, nullptr);
+    if (precision == FD_PREC_F16X3) launch_gemm_img(EPI_IMG_BIAS, g, (int)rows, nullptr);
     else launch_gemm_f32(EPI_BIAS, dA, dW, db, nullptr, dC, M, N, K, nullptr);
   };
   for (int i = 0; i < 3; ++i) run();
@@ -1479,7 +1457,8 @@ int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int rep
   T_TRY(hipEventElapsedTime(&ms, e0, e1));
 #undef T_TRY
   *ms_per_launch = ms / reps;
-  cleanup();
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return FD_OK;
 }
 

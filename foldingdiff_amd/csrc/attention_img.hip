@@ -37,36 +37,44 @@ __device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp
 
 constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-template <int T>
+template <int T, bool ELDS>
 struct Geo {
   static constexpr int LP = 32 * T;
-  static constexpr int Q_BYTES = LP * 128, K_BYTES = LP * KROW, V_BYTES = LP * 128;
-  static constexpr int QC = ceil_div(Q_BYTES, 1024), KC = ceil_div(K_BYTES, 1024), VC = ceil_div(V_BYTES, 1024);
-  static constexpr int QW = ceil_div(QC, 4), KW = ceil_div(KC, 4), VW = ceil_div(VC, 4);  // DMA pieces per wave
-  static constexpr int OFF_Q = 0, OFF_K = OFF_Q + QW * 4 * 1024, OFF_V = OFF_K + KW * 4 * 1024,
-                       OFF_R = OFF_V + VW * 4 * 1024;
-  static constexpr int SMEM_REL = OFF_R + 4 * 32 * RLD * 4, SMEM_ABS = OFF_R;
+  static constexpr int K_BYTES = LP * KROW, V_BYTES = LP * 128;
+  static constexpr int KC = ceil_div(K_BYTES, 1024), VC = ceil_div(V_BYTES, 1024);
+  static constexpr int KW = ceil_div(KC, 4), VW = ceil_div(VC, 4);  // DMA pieces per wave (4 waves per group)
+  static constexpr int E_BYTES = ELDS ? 32 * 1024 : 0;              // distance table image, 255 rows x 128 B (maxpos <= 128)
+  static constexpr int OFF_K = 0, OFF_V = OFF_K + KW * 4 * 1024, OFF_R = OFF_V + VW * 4 * 1024;
+  static constexpr int G_REL = OFF_R + 4 * 32 * RLD * 4, G_ABS = OFF_R;  // bytes per group
 };
 
+// Two 4-wave groups per workgroup (8 waves, one workgroup per CU), each group walking its own stream of
+// (item, key tile) positions in lockstep with the other (shared barriers), both sharing ONE copy of the distance
+// table in LDS (ELDS: single key tile and maxpos <= 128, i.e. every released configuration).  With the table in LDS the
+// S / band phase issues no vector-memory instruction at all, so the K / V copies in flight are never waited for early
+// (loads retire in order: a table fetch from L2 behind a V copy used to stall the band phase until V had landed).
+// Q comes straight from global memory into registers, one item ahead.
 // SAFE: every wait is vmcnt(0) (debug aid for the counted-wait bookkeeping)
-template <int T, bool REL, bool SAFE, bool PROF = false>
-__global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
-  using G = Geo<T>;
+template <int T, bool REL, bool ELDS, bool SAFE, bool PROF = false>
+__global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
+  using G = Geo<T, ELDS>;
   constexpr int LP = G::LP;
+  constexpr int GSZ = REL ? G::G_REL : G::G_ABS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Qs = smem + G::OFF_Q;
-  unsigned char* Ks = smem + G::OFF_K;
-  unsigned char* Vt = smem + G::OFF_V;
-  float* Rs = reinterpret_cast<float*>(smem + G::OFF_R);
-
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wq = wid & 3;
   const int half = lane >> 5, l31 = lane & 31;
+  unsigned char* Es = smem;
+  unsigned char* gbase = smem + G::E_BYTES + grp * GSZ;
+  unsigned char* Ks = gbase + G::OFF_K;
+  unsigned char* Vt = gbase + G::OFF_V;
+  float* Rw = reinterpret_cast<float*>(gbase + G::OFF_R) + wq * 32 * RLD;
   const int H = p.H, nqg = p.NKT;  // query groups == key tiles
   const int nitems = p.B * H * nqg;
-  float* Rw = Rs + wq * 32 * RLD;
+  const int gstride = 2 * gridDim.x;
 
-  // ---- the stream of (item, key tile) positions of this workgroup
+  // ---- the stream of (item, key tile) positions of this group: items 2 blockIdx + grp, + 2 gridDim, ...
   struct Pos { int item, kt, b, h, qg, len, nkt; };
   auto load_item = [&](Pos& s, int item) {
     s.item = item;
@@ -80,11 +88,23 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
   };
   auto advance = [&](Pos& s) {  // next position; past the end it stays on the last one (copies are repeated, harmlessly)
     if (s.kt + 1 < s.nkt) { ++s.kt; return; }
-    if (s.item + (int)gridDim.x < nitems) load_item(s, s.item + gridDim.x);
+    if (s.item + gstride < nitems) load_item(s, s.item + gstride);
   };
-  auto is_last = [&](const Pos& s) { return s.kt + 1 >= s.nkt && s.item + (int)gridDim.x >= nitems; };
+  auto is_last = [&](const Pos& s) { return s.kt + 1 >= s.nkt && s.item + gstride >= nitems; };
+  // positions of a group's stream (both groups loop to the longer one: the barriers are shared)
+  auto stream_len = [&](int g) {
+    int n = 0;
+    for (int it = 2 * blockIdx.x + g; it < nitems; it += gstride) {
+      const int bb = it / (nqg * H);
+      n += (p.lens[bb] + LP - 1) / LP;
+    }
+    return n;
+  };
+  const int my_len = stream_len(grp), other_len = stream_len(grp ^ 1);
+  const int niter = my_len > other_len ? my_len : other_len;
+  const bool has_work = my_len > 0;
 
-  // linear LDS-DMA copies; wave w takes pieces w, w + 4, ...; indices past the end repeat the last piece
+  // linear LDS-DMA copies; wave wq of the group takes pieces wq, wq + 4, ...; indices past the end repeat the last piece
   auto copy = [&](const unsigned char* src, int bytes, int npieces, int per_wave, unsigned char* dst_base) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, bytes, 0x00020000);
 #pragma unroll
@@ -94,23 +114,41 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
       dma16(rs, (lds_ptr_t)(dst_base) + piece * 1024, lane * 16, piece * 1024);
     }
   };
-  auto issue_kq = [&](const Pos& s, bool with_q) {
+  auto issue_k = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
     copy(p.kbuf + (bh * p.LTOT + (size_t)s.kt * LP) * KROW, G::K_BYTES, G::KC, G::KW, Ks);
-    if (with_q) copy(p.qbuf + (bh * p.LTOT + (size_t)s.qg * LP) * 128, G::Q_BYTES, G::QC, G::QW, Qs);
   };
   auto issue_v = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
     copy(p.vbuf + (bh * p.LTOT + (size_t)s.kt * LP) * 128, G::V_BYTES, G::VC, G::VW, Vt);
   };
+  // Q operand of this lane: query l31 of the wave's row block, d = 16c + 8 half + j: units 2c + half (hi), 4 + 2c + half (lo)
+  auto load_q = [&](const Pos& s, u32x4 (&q)[4]) {
+    const size_t bh = (size_t)s.b * H + s.h;
+    const u32x4* row = reinterpret_cast<const u32x4*>(p.qbuf + (bh * p.LTOT + (size_t)s.qg * LP + 32 * (wq < T ? wq : 0) + l31) * 128);
+    q[0] = row[half]; q[1] = row[2 + half]; q[2] = row[4 + half]; q[3] = row[6 + half];
+  };
 
-  if ((int)blockIdx.x >= nitems) return;
   Pos cur, nxt;
-  load_item(cur, blockIdx.x);
-  issue_kq(cur, true);
+  load_item(cur, 2 * blockIdx.x + grp);
+  u32x4 qn[4];
+  if constexpr (REL && ELDS) {
+    // distance table -> LDS once per workgroup: 32 pieces of 8 rows, unit u of row m stored at u ^ ((m >> 1) & 7)
+    const int nrow_e = 2 * p.maxpos - 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.demb)), 0, nrow_e * 128, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wid + 8 * i;  // rows 8 piece .. 8 piece + 7
+      const int row = 8 * piece + (lane >> 3);
+      dma16(rs, (lds_ptr_t)(Es) + piece * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4), 0);
+    }
+  }
+  issue_k(cur);
+  load_q(cur, qn);
   issue_v(cur);
   nxt = cur;
-  bool done = is_last(cur);
+  bool done = is_last(cur) || !has_work;
   advance(nxt);
 
   const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
@@ -119,22 +157,23 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc;
   bool stored_prev = false;  // the previous position ended an item (4 ctx stores are younger than its V copy)
-  const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
+  const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr && grp == 0;
   unsigned long long* st = PROF ? p.stamps + (size_t)wq * 64 * 8 : nullptr;
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
-  for (;;) {
+  for (int iter = 0; iter < niter; ++iter) {
     FD_STAMP(0);
+    const bool live = iter < my_len;  // this group still has positions (otherwise it only keeps the barriers company)
     const int b = cur.b, h = cur.h, qg = cur.qg, kt = cur.kt, len = cur.len;
     const int row0 = p.seq_row0[b];
     const int nrows = p.seq_row0[b + 1] - row0;  // token rows of the sequence (multiple of 8, >= real rows)
     const int Lb = p.nrow[b];                    // real rows: positions >= Lb are not keys at all
     const int l0 = qg * LP + 32 * wq;
-    const bool active = wq < T && l0 < nrows;
+    const bool active = live && wq < T && l0 < nrows;
     const int r0 = kt * LP;
     const bool first_tile = kt == 0;
-    const bool nxt_first = nxt.kt == 0 && !done;  // does the next position start an item (its Q travels with its K)
+    const bool nxt_first = nxt.kt == 0 && !done;  // the next position starts an item: its Q is fetched with its K
 
     // ---- [A] K(p) (+ Q(p)) landed.  Younger: V(p) pieces, and the ctx stores of the previous position.
     if (SAFE) FD_WAIT_VM(0);
@@ -144,11 +183,10 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
     barrier_keep_vm();
     FD_STAMP(2);
     if (first_tile) {
-      const unsigned char* qrow = Qs + (size_t)(32 * (wq < T ? wq : 0) + l31) * 128;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        qh[c] = *reinterpret_cast<const f16x8*>(qrow + 32 * c + 16 * half);
-        ql[c] = *reinterpret_cast<const f16x8*>(qrow + 64 + 32 * c + 16 * half);
+        qh[c] = __builtin_bit_cast(f16x8, qn[c]);
+        ql[c] = __builtin_bit_cast(f16x8, qn[2 + c]);
       }
       m_run = -INFINITY;
       l_run = 0.f;
@@ -184,8 +222,18 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
         for (int qq = 0; qq <= T; ++qq) {
           int m = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * qq;
           m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
-          const u32x4_t* erow = p.demb + (size_t)m * 8;  // 128-byte image: units 0-3 hi d0-31, 4-7 lo
-          const u32x4 e0 = erow[half], e1 = erow[2 + half], e2 = erow[4 + half], e3 = erow[6 + half];
+          u32x4 e0, e1, e2, e3;  // units half, 2 + half (hi d 0-15 / 16-31), 4 + half, 6 + half (lo)
+          if constexpr (ELDS) {
+            const unsigned char* erow = Es + m * 128;
+            const int sz = (m >> 1) & 7;
+            e0 = *reinterpret_cast<const u32x4*>(erow + ((half ^ sz) << 4));
+            e1 = *reinterpret_cast<const u32x4*>(erow + (((2 + half) ^ sz) << 4));
+            e2 = *reinterpret_cast<const u32x4*>(erow + (((4 + half) ^ sz) << 4));
+            e3 = *reinterpret_cast<const u32x4*>(erow + (((6 + half) ^ sz) << 4));
+          } else {
+            const u32x4_t* erow = p.demb + (size_t)m * 8;
+            e0 = erow[half]; e1 = erow[2 + half]; e2 = erow[4 + half]; e3 = erow[6 + half];
+          }
           f32x16 racc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) racc[r] = 0.f;
@@ -232,10 +280,11 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
       }
     }
 
-    // ---- [B] every wave is done with K (and Q): copy the next position's K (and Q)
+    // ---- [B] every wave is done with K: copy the next position's K, fetch the next item's Q
     FD_STAMP(3);
     barrier_keep_vm();
-    issue_kq(nxt, nxt_first);
+    issue_k(nxt);
+    if (nxt_first) load_q(nxt, qn);
     FD_STAMP(4);
 
     if (active) {
@@ -280,9 +329,9 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
       for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
     }
 
-    // ---- [C] V(p) landed.  Younger: the K (+ Q) pieces just issued.
+    // ---- [C] V(p) landed.  Younger: the K pieces (+ Q loads) just issued.
     if (SAFE) FD_WAIT_VM(0);
-    else if (nxt_first) FD_WAIT_VM(G::KW + G::QW);
+    else if (nxt_first) FD_WAIT_VM(G::KW + 4);
     else FD_WAIT_VM(G::KW);
     FD_STAMP(5);
     barrier_keep_vm();
@@ -340,19 +389,20 @@ __global__ __launch_bounds__(256, 2) void attn_img_kernel(AttnImgArgs p) {
       store_block(dst, o, p.ctx_scale, half, true);
     }
     stored_prev = item_ends;
-    if (done) break;
-    cur = nxt;
-    done = is_last(cur);
-    advance(nxt);
+    if (!done) {
+      cur = nxt;
+      done = is_last(cur);
+      advance(nxt);
+    }
   }
 #undef FD_STAMP
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
-template <int T, bool REL>
+template <int T, bool REL, bool ELDS>
 static void launch(const AttnImgArgs& p, hipStream_t s) {
-  using G = Geo<T>;
-  constexpr int smem = REL ? G::SMEM_REL : G::SMEM_ABS;
+  using G = Geo<T, ELDS>;
+  constexpr int smem = G::E_BYTES + 2 * (REL ? G::G_REL : G::G_ABS);
   static const bool safe = [] { const char* e = getenv("FDMI_ATTN_SAFE"); return e && atoi(e) != 0; }();
   static bool attr_set[64] = {false};
   static int n_cu[64] = {0};
@@ -360,22 +410,22 @@ static void launch(const AttnImgArgs& p, hipStream_t s) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipDeviceProp_t prop;
     n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     attr_set[dev] = true;
   }
   const int nitems = p.B * p.H * p.NKT;
-  int grid = 2 * n_cu[dev];  // two 4-wave workgroups per CU (registers: 2 waves per SIMD)
-  if (grid > nitems) grid = nitems;
-  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, false, true>), dim3(grid), dim3(256), smem, s, p);
-  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, true>), dim3(grid), dim3(256), smem, s, p);
-  else hipLaunchKernelGGL((attn_img_kernel<T, REL, false>), dim3(grid), dim3(256), smem, s, p);
+  int grid = n_cu[dev];  // one 8-wave workgroup (two item streams) per CU
+  if (grid > (nitems + 1) / 2) grid = (nitems + 1) / 2;
+  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, false, true>), dim3(grid), dim3(512), smem, s, p);
+  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, true>), dim3(grid), dim3(512), smem, s, p);
+  else hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, false>), dim3(grid), dim3(512), smem, s, p);
 }
 
 }  // namespace ai
@@ -384,10 +434,12 @@ bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s) {
   if (L < 1) return false;
   const int T = L > 128 ? 4 : (L + 31) / 32;  // keys per tile = 32 T; L > 128: 128-key tiles, online softmax
   const bool rel = p.demb != nullptr;
-#define FD_ATTN_IMG_CASE(TT)                       \
-  case TT:                                         \
-    if (rel) ai::launch<TT, true>(p, s);           \
-    else ai::launch<TT, false>(p, s);              \
+  const bool elds = rel && p.NKT == 1 && p.maxpos <= 128;  // the whole distance table fits 32 KB of LDS
+#define FD_ATTN_IMG_CASE(TT)                                   \
+  case TT:                                                     \
+    if (!rel) ai::launch<TT, false, false>(p, s);              \
+    else if (elds) ai::launch<TT, true, true>(p, s);           \
+    else ai::launch<TT, true, false>(p, s);                    \
     break;
   switch (T) {
     FD_ATTN_IMG_CASE(1)

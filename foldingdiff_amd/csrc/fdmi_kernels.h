@@ -21,26 +21,10 @@ enum GemmEpilogue {
 void launch_gemm_f32(int epilogue, const float* A, const float* W, const float* bias, const float* resid, float* C,
                      int M, int N, int K, hipStream_t s);
 
-// fp16x3 split-precision GEMM (three v_mfma_f32_32x32x16_f16 per product, fp32-class accuracy).
-// Wp: weight pre-split by pack_split_weight() (host) into [Npad128][K/32][hi x32 | lo x32] fp16,
-// scaled by the power of two w_scale.  K % 32 == 0.
-void launch_gemm_f16x3(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias,
-                       const float* resid, float* C, int M, int N, int K, hipStream_t s);
-
 // Fused GEMM + bias + residual + LayerNorm over full rows (N == 384 or 192):
 //   C = LN(A * W^T + bias + resid) * gamma + beta.   Returns false if (N) has no instantiation.
 bool launch_gemm_f32_ln(const float* A, const float* W, const float* bias, const float* resid, const float* gamma,
                         const float* beta, float eps, float* C, int M, int N, int K, hipStream_t s);
-
-// The same fusion in fp16x3 split arithmetic (N == 384, K % 64 == 0, K >= 128); false otherwise.
-bool launch_gemm_f16x3_ln(const float* A, const void* Wp, float w_scale, const float* bias, const float* resid,
-                          const float* gamma, const float* beta, float eps, float* C, int M, int N, int K,
-                          hipStream_t s);
-
-// Plain-epilogue (bias | bias + GELU) GEMM on the 128 x 384 tiling of the LN-fused kernel; false if disabled
-// (FDMI_GEMM_WIDE=0) or the shape does not fit (N % 384, M % 128, K % 64) -- callers fall back to launch_gemm_f16x3.
-bool launch_gemm_f16x3_wide(int epilogue, const float* A, const void* Wp, float w_scale, const float* bias, float* C,
-                            int M, int N, int K, hipStream_t s);
 
 // y[r,:] = LN(x[r,:]) * gamma + beta, rows of length d (d <= 1024), one wave per row.
 void launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int d,
@@ -57,12 +41,6 @@ void launch_embed(const float* x, const float* w_in, const float* b_in, const fl
 // Returns false when L is beyond what this build tiles (L > 128).
 bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
                           int maxpos, hipStream_t s);
-
-// Same contract, contractions as fp16 hi/lo split triples on v_mfma_f32_32x32x16_f16 (fp32-class accuracy).
-// dist_emb_split: the layer's [2*maxpos-1, 32] table pre-split into 128-byte fp16 row images (hi x32 | lo x32),
-// scaled by the power of two table_scale (null for absolute positions).
-bool launch_attention_f16x3(const float* qkv, const void* dist_emb_split, float table_scale, const int* lens,
-                            float* ctx, int B, int L, int H, int maxpos, hipStream_t s);
 
 // K8 tail + K9: per token  y = do_ln ? LN(g)*gamma+beta : g ;  eps = y W2^T + b2 ;
 //   x' = wrap_if_angle( c1[t] * (x - beta[t]*eps / c3[t]) + (t>0 ? sigma[t]*z : 0) )

@@ -67,6 +67,27 @@ def gather_final(local: torch.Tensor, counts: Sequence[int], group=None) -> Opti
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
 
 
+def all_gather_batches(local: torch.Tensor, counts: Sequence[int], device=None, group=None) -> torch.Tensor:
+    """ONE collective: every rank contributes its [b_r, ...] block and EVERY rank gets the concatenation in rank
+    order.  ``device``: where the collective runs -- the model's GPU under "nccl" (= RCCL over xGMI), ignored
+    under "gloo".  The result comes back on ``local``'s device."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(counts) == world and local.shape[0] == counts[rank]
+    home = local.device
+    if dist.get_backend(group) == "nccl":
+        local = local.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    bmax = max(counts)
+    pad = local
+    if local.shape[0] != bmax:
+        pad = torch.zeros((bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    out = torch.empty((world * bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    out = out.view((world, bmax) + tuple(local.shape[1:]))
+    return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0).to(home)
+
+
 def sample_sharded(
     run_local: Callable[[int, int], torch.Tensor],
     n_items: int,

@@ -33,7 +33,7 @@ import torch
 from . import _binding, beta_schedules
 from .datasets import FEATURE_SET_NAMES_TO_ANGULARITY
 
-DEFAULT_PRECISION = "f16x3"  # fp32-class accuracy (measured <= the exact-fp32 kernels' error), ~2x faster
+DEFAULT_PRECISION = "f16x3"  # fp16 hi/lo split on the fp16 matrix cores: fp32-class accuracy (measured <= the exact-fp32 kernels' error), > 2x faster
 TIME_ENCODING = Literal["gaussian_fourier", "sinusoidal"]
 DECODER_HEAD = Literal["mlp", "linear"]
 
@@ -355,6 +355,10 @@ class BertForDiffusionBase:
         assert len(is_angle) == self.n_inputs
         if self.precision not in _binding.FD_PREC:
             raise ValueError(f"precision={self.precision!r}; expected one of {sorted(_binding.FD_PREC)}")
+        if self.precision == "f16x3" and self.config.hidden_size > 384:
+            # the split path fuses whole LayerNorm rows into one 384-column workgroup tile
+            logging.warning("hidden_size=%d > 384: using the exact-fp32 kernels (precision 'f32')", self.config.hidden_size)
+            self.precision = "f32"
         key = (betas.numel(), betas.numpy().tobytes(), tuple(bool(a) for a in is_angle), self.precision)
         if self._betas_key == key:
             return h
@@ -403,6 +407,12 @@ class BertForDiffusionBase:
         forward itself does not read them)."""
         assert attention_mask is not None
         assert inputs.dim() == 3
+        if position_ids is not None:
+            # the reference honours position_ids with absolute embeddings (modelling.py:434-442); the device kernels
+            # always use 0 .. L-1 -- refuse anything else instead of silently computing a different function
+            want = torch.arange(inputs.shape[1]).expand(inputs.shape[0], -1)
+            if tuple(position_ids.shape) != tuple(want.shape) or not torch.equal(position_ids.detach().cpu().long(), want):
+                raise NotImplementedError("position_ids other than arange(seq_len) are not supported")
         lens = self.lengths_from_mask(attention_mask)
         t = timestep.detach().cpu().reshape(-1).long()
         assert t.numel() == inputs.shape[0]

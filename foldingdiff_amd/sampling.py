@@ -36,7 +36,7 @@ def _as_f32(t: torch.Tensor) -> np.ndarray:
 
 
 def _lens_array(seq_lens: Sequence[int], B: int, L: int) -> np.ndarray:
-    lens = np.ascontiguousarray(np.asarray(list(seq_lens), dtype=np.int32))
+    lens = np.ascontiguousarray(np.asarray(seq_lens, dtype=np.int32).reshape(-1))  # a (B, 1) tensor is fine, as in the reference
     assert lens.shape == (B,), f"need one length per batch item, got {lens.shape} for batch {B}"
     if lens.min() < 1 or lens.max() > L:
         raise ValueError(f"sequence lengths must lie in [1, {L}], got [{lens.min()}, {lens.max()}]")
@@ -54,6 +54,7 @@ def p_sample(model, x: torch.Tensor, t: torch.Tensor, seq_lens: Sequence[int], t
     h = model.prepare(betas)
     xs = _as_f32(x)
     B, L, F = xs.shape
+    assert F == model.n_inputs, f"{F} features, the model takes {model.n_inputs}"
     lens = _lens_array(seq_lens, B, L)
     z = _as_f32(torch.randn_like(x)) if ti > 0 else None
     out = np.empty_like(xs)
@@ -61,6 +62,11 @@ def p_sample(model, x: torch.Tensor, t: torch.Tensor, seq_lens: Sequence[int], t
         h, xs.ctypes.data_as(C.c_void_p), ti, lens.ctypes.data_as(C.c_void_p), B, L,
         z.ctypes.data_as(C.c_void_p) if z is not None else None, 0, out.ctypes.data_as(C.c_void_p)))
     return torch.from_numpy(out).to(x.device)
+
+
+def _draw_philox_seed() -> int:
+    """64-bit seed of the on-device generator, drawn from torch's CPU generator (torch.manual_seed reproducible)."""
+    return int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
 
 
 def _draw_step_noise(T: int, shape) -> np.ndarray:
@@ -71,6 +77,17 @@ def _draw_step_noise(T: int, shape) -> np.ndarray:
     for i in reversed(range(1, T)):
         noise[i] = torch.randn(tuple(shape), dtype=torch.float32).numpy()
     return noise
+
+
+def _run_fd_sample(h, x0: np.ndarray, lens: np.ndarray, t_start: int, zs: Optional[np.ndarray], seed: int,
+                   seq_offset: int, out: np.ndarray, full_history: int) -> None:
+    """The one call into libfdmi.so that runs reverse steps t_start .. 0 on a host batch (fd_sample_ex).  Tests of
+    the multi-process path replace exactly this function with a CPU stand-in."""
+    B, L, _ = x0.shape
+    _binding.check(_binding.load().fd_sample_ex(
+        h, x0.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, L, t_start,
+        zs.ctypes.data_as(C.c_void_p) if zs is not None else None, C.c_uint64(seed), C.c_int64(seq_offset),
+        out.ctypes.data_as(C.c_void_p), full_history))
 
 
 @torch.no_grad()
@@ -84,6 +101,9 @@ def p_sample_loop(
     disable_pbar: bool = False,
     final_only: bool = False,
     history_every: int = 1,
+    step_noise: Optional[np.ndarray] = None,
+    seed: Optional[int] = None,
+    seq_offset: int = 0,
 ) -> torch.Tensor:
     """Run the whole reverse process from ``noise``.  Returns a CPU tensor of shape
     (timesteps, batch_size, seq_len, n_ft) -- entry j is the state after step
@@ -95,25 +115,28 @@ def p_sample_loop(
     assert len(betas) == timesteps, f"{len(betas)} betas for {timesteps} timesteps"
     if not isinstance(is_angle, bool):
         assert len(is_angle) == noise.shape[-1]
+    assert noise.shape[-1] == model.n_inputs, f"{noise.shape[-1]} features, the model takes {model.n_inputs}"
     h = model.prepare(betas, is_angle)
     x0 = _as_f32(noise)
     B, L, F = x0.shape
     lens = _lens_array(lengths, B, L)
     logging.info(f"Starting from noise {tuple(noise.shape)} with angularity {is_angle} using {model.device}")
-    lib = _binding.load()
-    if NOISE_MODE == "torch":
-        zs = _draw_step_noise(timesteps, (B, L, F))
-        zptr, seed = zs.ctypes.data_as(C.c_void_p), 0
+    # per-step noise: given by the caller (a slice of a larger batch's draws), else drawn here
+    if step_noise is not None:
+        zs = np.ascontiguousarray(step_noise, dtype=np.float32)
+        assert zs.shape == (timesteps, B, L, F)
+        seed = 0
+    elif seed is not None:
+        zs = None
+    elif NOISE_MODE == "torch":
+        zs, seed = _draw_step_noise(timesteps, (B, L, F)), 0
     elif NOISE_MODE == "philox":
-        zs, zptr = None, None
-        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        zs, seed = None, _draw_philox_seed()
     else:
         raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
     rows = 1 if final_only else -(-timesteps // history_every)
     out = np.empty((rows, B, L, F), dtype=np.float32)
-    _binding.check(lib.fd_sample(h, x0.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, L,
-                                 timesteps - 1, zptr, C.c_uint64(seed), out.ctypes.data_as(C.c_void_p),
-                                 0 if final_only else history_every))
+    _run_fd_sample(h, x0, lens, timesteps - 1, zs, seed, seq_offset, out, 0 if final_only else history_every)
     return torch.from_numpy(out)
 
 
@@ -142,6 +165,7 @@ def sample_on_device(
     x_init, lens = x_init.contiguous(), lens.contiguous()
     h = model.prepare(betas, is_angle)
     B, L, F = x_init.shape
+    assert F == model.n_inputs, f"{F} features, the model takes {model.n_inputs}"
     T = len(betas)
     t_start = T - 1 if t_start is None else t_start
     hist = int(full_history)   # 0 final only, 1 every state, k every k-th state
@@ -164,7 +188,16 @@ def sample_on_device(
         None if own_stream else C.c_void_p(ts.cuda_stream)))
     if own_stream and sync:
         _binding.check(lib.fd_synchronize(h))
+        _binding.check(lib.fd_check_finite(h))  # FD_E_NONFINITE if the model output went inf / NaN at some step
     return out
+
+
+def _dist_world():
+    """(world size, rank) of the default process group, (1, 0) when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
 
 
 def sample(
@@ -188,7 +221,17 @@ def sample(
 
     ``train_dset`` needs ``sample_noise``, ``timesteps``, ``alpha_beta_terms``,
     ``feature_is_angular``, ``pad`` (and optionally ``sample_length``,
-    ``dset.get_masked_means``), as the reference documents."""
+    ``dset.get_masked_means``), as the reference documents.
+
+    Positions beyond an item's length are cut away below (as in the reference, sampling.py:201-203), so the device
+    does not compute them at all (option "varlen": token rows = sum of lengths instead of batch x longest).
+
+    Multi-GPU (extension; the reference is single device): when ``torch.distributed`` is initialised -- e.g.
+    ``torchrun bin/sample.py`` with one process per GPU -- every rank draws the same start / step noise (same torch
+    seed, as a replicated run of the reference would), runs the reverse process on a token-balanced slice of each
+    batch only, and ONE all-gather per batch gives every rank the complete result, identical to a single-GPU run."""
+    from . import distributed as fdist
+
     if sweep_lengths is not None:
         lo, hi = sweep_lengths
         if not lo < hi:
@@ -198,17 +241,42 @@ def sample(
     else:
         lengths = [train_dset.sample_length() for _ in range(n)]
     logging.info(f"Sampling {len(lengths)} items in batches of size {batch_size}")
+    world, rank = _dist_world()
+    T = train_dset.timesteps
     results: List[np.ndarray] = []
     for start in range(0, len(lengths), batch_size):
         these = lengths[start : start + batch_size]
         noise = train_dset.sample_noise(torch.zeros((len(these), train_dset.pad, model.n_inputs), dtype=torch.float32))
         if trim_to_length:
             noise = noise[:, : max(these), :]
-        traj = p_sample_loop(
-            model=model, lengths=these, noise=noise, timesteps=train_dset.timesteps,
-            betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
-            disable_pbar=disable_pbar, final_only=final_only, history_every=history_every)
-        results.extend(traj[:, i, :l, :].numpy() for i, l in enumerate(these))
+        B, L, F = noise.shape
+        # per-step noise of the WHOLE batch in the reference's draw order: identical on every rank, sliced below
+        if NOISE_MODE == "torch":
+            zs, seed = _draw_step_noise(T, (B, L, F)), None
+        elif NOISE_MODE == "philox":
+            zs, seed = None, _draw_philox_seed()
+        else:
+            raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
+        bounds = fdist.shard_by_tokens(these, world) if world > 1 else [(0, B)]
+        lo, hi = bounds[rank]
+        rows = 1 if final_only else -(-T // history_every)
+        if hi > lo:
+            model.set_option("varlen", 1)
+            try:
+                traj = p_sample_loop(
+                    model=model, lengths=these[lo:hi], noise=noise[lo:hi], timesteps=T,
+                    betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
+                    disable_pbar=disable_pbar, final_only=final_only, history_every=history_every,
+                    step_noise=None if zs is None else zs[:, lo:hi], seed=seed, seq_offset=lo)
+            finally:
+                model.set_option("varlen", 0)
+        else:
+            traj = torch.zeros((rows, 0, L, F), dtype=torch.float32)
+        if world > 1:  # the single exchange of the path: [b_r, rows, L, F] blocks -> every rank holds the whole batch
+            device = getattr(model, "device", torch.device("cpu"))
+            full = fdist.all_gather_batches(traj.permute(1, 0, 2, 3).contiguous(), [h_ - l_ for l_, h_ in bounds], device)
+            traj = full.permute(1, 0, 2, 3)
+        results.extend(traj[:, i, :l, :].numpy().copy() for i, l in enumerate(these))
     inner = getattr(train_dset, "dset", None)
     offset = None
     if inner is not None and hasattr(inner, "get_masked_means"):
@@ -240,18 +308,16 @@ def reverse_from(model, x_t: torch.Tensor, lengths: Sequence[int], t_start: int,
     h = model.prepare(betas, is_angle)
     x0 = _as_f32(x_t)
     B, L, F = x0.shape
+    assert F == model.n_inputs, f"{F} features, the model takes {model.n_inputs}"
     lens = _lens_array(lengths, B, L)
     if NOISE_MODE == "torch":
-        zs = _draw_step_noise(t_start + 1, (B, L, F))
-        zptr, seed = zs.ctypes.data_as(C.c_void_p), 0
+        zs, seed = _draw_step_noise(t_start + 1, (B, L, F)), 0
     elif NOISE_MODE == "philox":
-        zs, zptr = None, None
-        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        zs, seed = None, _draw_philox_seed()
     else:
         raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
     out = np.empty((1, B, L, F), dtype=np.float32)
-    _binding.check(_binding.load().fd_sample(h, x0.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, L,
-                                             t_start, zptr, C.c_uint64(seed), out.ctypes.data_as(C.c_void_p), 0))
+    _run_fd_sample(h, x0, lens, t_start, zs, seed, 0, out, 0)
     return torch.from_numpy(out[0])
 
 

@@ -154,6 +154,11 @@ int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, in
 int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
               uint64_t seed, float* out, int full_history);
 
+/* fd_sample for a slice of a larger batch: `seq_offset` is the global index of sequence 0, added to the sequence
+ * index in the Philox key (multi-GPU sharding of sampling.sample: every rank draws the noise of the unsharded batch). */
+int fd_sample_ex(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,
+                 uint64_t seed, int64_t seq_offset, float* out, int full_history);
+
 /* Same, with every buffer already resident in device memory, asynchronous on
  * `hip_stream` (a hipStream_t, NULL = the model's own stream).  The caller
  * synchronises.  `seq_offset` is added to the sequence index in the Philox key

@@ -66,3 +66,84 @@ def test_two_rank_gloo_gather(n_items):
     assert got.shape == (n_items, 5, 6)
     for i in range(n_items):
         assert (got[i] == i + 0.25).all()
+
+
+# ------------------------------------------------------------------ sampling.sample under torch.distributed
+# The product function itself (sharding by tokens, slicing of the start / step noise, seq_offset, the ONE all-gather,
+# trimming, identical result on every rank) with the device sampler replaced at the fd_sample_ex boundary only.
+class _StubModel:
+    n_inputs = 6
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.opts = []
+
+    def prepare(self, betas, is_angle=None):
+        return None
+
+    def set_option(self, name, value):
+        self.opts.append((name, value))
+
+
+def _stub_fd_sample(h, x0, lens, t_start, zs, seed, seq_offset, out, full_history):
+    """CPU stand-in for libfdmi's fd_sample_ex: a deterministic function of exactly what the device sampler consumes
+    (start noise, lengths, the step-noise slice or the Philox seed, the GLOBAL sequence index)."""
+    import numpy as np
+    B, L, _ = x0.shape
+    val = 0.5 * x0
+    if zs is not None:
+        val = val + 0.01 * zs[1:].sum(axis=0)
+    else:
+        val = val + 1e-3 * (seed % 97)
+    val = val + (np.arange(B) + seq_offset)[:, None, None]
+    real = np.arange(L)[None, :, None] < lens[:, None, None]
+    out[:] = np.where(real, val, np.nan)[None].astype(np.float32)   # padded positions must never reach a result
+
+
+def _run_sample(mode):
+    from foldingdiff_amd import datasets, sampling
+    sampling._run_fd_sample = _stub_fd_sample
+    sampling.NOISE_MODE = mode
+    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=32), timesteps=4,
+                                      beta_schedule="cosine")
+    torch.manual_seed(11)
+    model = _StubModel()
+    res = sampling.sample(model, ds, n=3, sweep_lengths=(5, 14), batch_size=16, final_only=True)
+    return res, model.opts
+
+
+def _sample_worker(rank, world, port, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res, opts = _run_sample(mode)
+        q.put((rank, [r.copy() for r in res], opts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["torch", "philox"])
+def test_sample_is_sharded_and_world_size_invariant(mode):
+    import numpy as np
+    want, opts1 = _run_sample(mode)                     # single process: torch.distributed not initialised
+    assert len(want) == 27 and [w.shape for w in want] == [(1, 5 + i // 3, 6) for i in range(27)]
+    assert all(np.isfinite(w).all() for w in want)
+    assert opts1 == [("varlen", 1), ("varlen", 0)] * 2  # two batches (16 + 11), padded positions not computed
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, res, opts = q.get(timeout=180)
+        got[rank] = res
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):                                  # every rank holds the complete, identical result
+        assert len(got[rank]) == 27
+        for a, b in zip(got[rank], want):
+            assert a.shape == b.shape and np.array_equal(a, b)
