@@ -22,6 +22,7 @@ The JSON line also carries
                 kernel instead of replaying the graph), against the dense fp32-MFMA peak.
   cpu_baseline  the reference CPU path (oracle restatement, "port") timed on this box's
                 host cores over a bounded sample of the same workload.
+  extras.c5     one pass of BASELINE config C5 (L = 512, batch 128, max_position_embeddings = 512).
 """
 import argparse
 import ctypes as C
@@ -41,12 +42,13 @@ RELEASED = dict(hidden_size=384, num_attention_heads=12, intermediate_size=768, 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (2:1-sparsity figures are NOT used)
 PEAK_HBM_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: measured float4 copy
 PRECISION_INFO = {
     "f32": dict(peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
                 kernel="gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384; v_mfma_f32_32x32x2_f32)"),
     "f16x3": dict(peak=PEAK_F16_MFMA_TFLOPS, dtype="f32 (fp16 hi/lo split operands, 3x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
-                  kernel="gemm_f16x3_ln_kernel<0,EPI_BIAS> = 128x384-tile split GEMM (QKV projection, M=B*L, N=1152, K=384; algorithmic FLOPs counted once, "
-                         "the 3 MFMAs per product are overhead against the dense fp16 peak)"),
+                  kernel="gi::gemm_img_kernel<EPI_IMG_QK> = 128x384-tile LDS-DMA-staged split GEMM on fp16 hi|lo row images (q|k projection, "
+                         "M=B*L, N=768, K=384; algorithmic FLOPs counted once, the 3 MFMAs per product are overhead against the dense fp16 peak)"),
 }
 
 
@@ -55,52 +57,47 @@ def flops_per_token(L, d=384, ff=768, layers=12, F=6):
     return layers * (8 * d * d + 4 * d * ff + 6 * L * d) + 2 * F * d + 2 * d * d + 2 * d * F
 
 
-def cpu_baseline(L, T, budget_s=15.0):
-    """Reference CPU path (oracle port of foldingdiff/sampling.py p_sample_loop + the restated
-    BertForDiffusion), all host cores, on a bounded sample: a few consecutive reverse steps at a
-    reduced batch, extrapolated to T steps (steps are homogeneous)."""
+def cpu_baseline(B, L, T, shape, steps=10):
+    """Reference CPU path (oracle port of foldingdiff/sampling.py p_sample_loop + the restated BertForDiffusion), host
+    cores of this box, on a bounded sample of the SAME workload: `steps` consecutive reverse steps at the
+    full batch, extrapolated to T steps (steps are homogeneous: same kernels, same shapes, t only indexes tables)."""
     from oracle import ref_model, ref_sampling
 
-    model = ref_model.synthetic_model(ref_model.OracleConfig(**RELEASED), seed=0, perturb=False)
-    Bc = 32
+    model = ref_model.synthetic_model(ref_model.OracleConfig(**shape), seed=0, perturb=False)
     betas = ref_sampling.beta_schedule("cosine", T)
     torch.manual_seed(0)
-    x = ref_sampling.initial_noise((Bc, L, 6), [True] * 6)
-    lens = [L] * Bc
 
-    def run(nsteps):
-        img = x.clone()
+    def run(nsteps, batch):
+        img = ref_sampling.initial_noise((batch, L, 6), [True] * 6)
+        lens = [L] * batch
         t0 = time.perf_counter()
         for i in reversed(range(T - nsteps, T)):
-            img = ref_sampling.p_sample(model, img, torch.full((Bc,), i, dtype=torch.long), lens, betas)
+            img = ref_sampling.p_sample(model, img, torch.full((batch,), i, dtype=torch.long), lens, betas)
             img = ref_sampling.wrap(img, -torch.pi, torch.pi)
         return time.perf_counter() - t0
 
-    # torch intra-op threads: all logical CPUs is rarely the fastest setting on a 2-socket SMT host
-    # (and a container may be cgroup-limited); try a few counts on one step each and keep the best.
+    # torch intra-op threads: all logical CPUs is rarely the fastest setting on a 2-socket SMT host (and a container may
+    # be cgroup-limited); probe a few counts on one step of a 1/8 batch and keep the best
     ncpu = os.cpu_count() or 1
-    cand = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    cand = sorted({c for c in (16, 32, 64, ncpu) if c <= ncpu})
     best, cores = None, cand[0]
+    pb = max(8, B // 8)
     for c in cand:
         torch.set_num_threads(c)
-        run(1)
-        dt = run(1)
+        run(1, pb)
+        dt = run(1, pb)
         if best is None or dt < best:
             best, cores = dt, c
-        if dt > 20:
-            break
     torch.set_num_threads(cores)
-    per_step = best
-    n = max(2, min(40, int(budget_s / max(per_step, 1e-3))))
-    per_step = run(n) / n
+    per_step = run(steps, B) / steps
     return {
-        "value": Bc / (per_step * T),
+        "value": B / (per_step * T),
         "unit": "backbones/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n} consecutive reverse steps at batch {Bc}, L={L} (of T={T}), torch fp32 eval-mode, "
-                  f"extrapolated x{T}/{n}; {per_step * 1e3:.1f} ms/step; best of torch thread counts {cand} "
-                  f"on {ncpu} logical CPUs",
+        "sample": f"{steps} consecutive reverse steps (t = {T - 1} .. {T - steps}) at the full batch {B}, L={L} (of T={T}), torch fp32 "
+                  f"eval-mode oracle, extrapolated x{T}/{steps}; {per_step * 1e3:.0f} ms/step; best of torch thread counts {cand} "
+                  f"(probed on batch {pb}) on {ncpu} logical CPUs",
     }
 
 
@@ -109,8 +106,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed passes (one pass = T reverse steps over the batch)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="sequences per GPU")
-    ap.add_argument("--length", type=int, default=128)
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"],
+                    help="BASELINE.json configuration: c2 = L 128, batch 512 (the headline metric); c5 = L 512, batch 128, "
+                         "max_position_embeddings 512 (long-chain stress)")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default: the configuration's)")
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--no-c5-extra", action="store_true", help="skip the extra BASELINE C5 pass reported in extras (N=1, c2 only)")
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--profile-every", type=int, default=100)
     ap.add_argument("--no-history", action="store_true", help="do not keep the [T,B,L,F] history in HBM")
@@ -140,9 +141,11 @@ def main():
     from foldingdiff_amd import _binding, beta_schedules, datasets, modelling, sampling
     from foldingdiff_amd import distributed as fdist
 
-    B, L, T = args.batch, args.length, args.timesteps
+    cfg_B, cfg_L = (512, 128) if args.config == "c2" else (128, 512)
+    B, L, T = args.batch or cfg_B, args.length or cfg_L, args.timesteps
+    shape = dict(RELEASED, max_position_embeddings=max(128, L))
     torch.manual_seed(0)
-    model = modelling.BertForDiffusionBase(modelling.BertConfig(**RELEASED), [True] * 6).to(dev)  # HF init, seed 0
+    model = modelling.BertForDiffusionBase(modelling.BertConfig(**shape), [True] * 6).to(dev)  # HF init, seed 0
     betas = beta_schedules.cosine_beta_schedule(T)
     if args.precision:
         model.set_precision(args.precision)
@@ -151,10 +154,10 @@ def main():
     if os.environ.get("FDMI_NO_GRAPH") == "1":  # e.g. under rocprofv3 --pmc
         model.set_option("use_graph", 0)
     lib = _binding.load()
-    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=128), timesteps=T,
+    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=max(128, L)), timesteps=T,
                                       beta_schedule="cosine")
     torch.manual_seed(7344 + rank)  # bin/sample.py:34-37 default seed
-    x_init = ds.sample_noise(torch.zeros(B, 128, 6))[:, :L].contiguous().to(dev)
+    x_init = ds.sample_noise(torch.zeros(B, max(128, L), 6))[:, :L].contiguous().to(dev)
     lens = torch.full((B,), L, dtype=torch.int32, device=dev)
     counts = [B] * world
     seq_offset = rank * B
@@ -215,6 +218,13 @@ def main():
     n_backbones = B * world * args.steps
     value = n_backbones / elapsed
     flop_per_backbone = flops_per_token(L) * L * T
+    # two-sided roofline of one timestep: algorithmic FLOPs against the MFMA peak of the instruction used (x3 MFMAs per
+    # product in the split arithmetic) and algorithmic HBM bytes (every activation read / written once per kernel, 4 B per
+    # element: the fp16 hi|lo images have the footprint of fp32) against the achievable HBM rate
+    per_step_launches = {"embed_ln_time": 1, "gemm_head_dense1": 1, "head_update_wrap": 1, "step_advance": 1}
+    hbm_bytes_step = sum(v["bytes"] * per_step_launches.get(k, RELEASED["num_hidden_layers"]) for k, v in kernels.items())
+    mfma_mult = 3.0 if model.precision == "f16x3" else 1.0
+    ms_step = elapsed / args.steps / T * 1e3
     dom = kernels.get("gemm_qkv")
     pinfo = PRECISION_INFO[model.precision]
     traffic = None
@@ -233,7 +243,7 @@ def main():
             "algorithmic_bytes_per_launch": dom["bytes"],
         }
     result = {
-        "metric": "backbones/sec (L=128, T=1000, bs=512)",
+        "metric": f"backbones/sec (L={L}, T={T}, bs={B})",
         "value": value,
         "unit": "backbones/s",
         "n_gpus": world,
@@ -245,7 +255,8 @@ def main():
         "vs_baseline": None,
         "dtype": pinfo["dtype"],
         "data": "synthetic",
-        "config": {"workload": f"C2: released foldingdiff_cath shape (d=384,H=12,d_ff=768,12 layers,relative_key), "
+        "config": {"workload": f"{args.config.upper()}: released foldingdiff_cath shape (d=384,H=12,d_ff=768,12 layers,relative_key"
+                               f"{', max_position_embeddings=512' if L > 128 else ''}), "
                                f"L={L}, T={T}, batch {B}/GPU, synthetic HF-init weights, Philox noise, "
                                f"history {'off' if args.no_history else 'in HBM'}",
                    "global_batch": B * world, "seq_len": L, "timesteps": T, "parallelism": f"batch-shard x{world}",
@@ -253,12 +264,19 @@ def main():
                    "gemm_precision": model.precision},
         "whole_step": {"algorithmic_tflops": value * flop_per_backbone / 1e12 / world,
                        "frac_of_mfma_peak": value * flop_per_backbone / 1e12 / world / pinfo["peak"],
-                       "ms_per_timestep": elapsed / args.steps / T * 1e3},
+                       "ms_per_timestep": ms_step,
+                       "hbm_algorithmic_bytes": hbm_bytes_step,
+                       "hbm_floor_ms": hbm_bytes_step / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3,
+                       "mfma_floor_ms": flops_per_token(L) * L * B * mfma_mult / (pinfo["peak"] * 1e12) * 1e3,
+                       "hbm_achieved_gbs": hbm_bytes_step / (ms_step * 1e-3) / 1e9,
+                       "note": "floors: HBM at the achievable 6.3 TB/s (8 TB/s peak), MFMA at the dense peak of the instruction "
+                               "used (3 MFMAs per product in f16x3); the GEMM k-loops are in fact bound by per-CU L2->LDS ingest "
+                               "(profiles/r02_gemm_ablation.log), which neither floor shows"},
         "roofline": roofline,
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
                         "launches": v["launches"]} for k, v in kernels.items()},
     }
-    if world == 1 and model.precision != "f32" and not args.no_exact_f32:
+    if world == 1 and model.precision != "f32" and not args.no_exact_f32 and L <= 128:
         # the same workload with every contraction on v_mfma_f32_32x32x2_f32 (bitwise-fp32 products), one pass
         model.set_precision("f32")
         model.prepare(betas)
@@ -272,8 +290,28 @@ def main():
         result["exact_f32_mode"] = {"value": B / dt, "unit": "backbones/s", "ms_per_step": dt * 1e3,
                                     "frac_of_f32_mfma_peak": (B / dt) * flop_per_backbone / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                     "note": "FD_PREC_F32: all GEMM/attention products on v_mfma_f32_32x32x2_f32, 1 timed pass"}
+    if world == 1 and args.config == "c2" and not args.no_c5_extra:
+        # BASELINE config C5 (L = 512 long-chain stress, batch 128, max_position_embeddings = 512): one timed pass
+        m5 = modelling.BertForDiffusionBase(modelling.BertConfig(**dict(RELEASED, max_position_embeddings=512)), [True] * 6).to(dev)
+        m5.set_precision(model.precision)
+        m5.prepare(betas)
+        x5 = ds.sample_noise(torch.zeros(128, 512, 6)).contiguous().to(dev)
+        l5 = torch.full((128,), 512, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(side):
+            sampling.sample_on_device(m5, x5, l5, betas, seed=1, t_start=1)  # workspace + graph
+        sync_all()
+        t5 = time.perf_counter()
+        with torch.cuda.stream(side):
+            o5 = sampling.sample_on_device(m5, x5, l5, betas, seed=2)
+        sync_all()
+        dt5 = time.perf_counter() - t5
+        assert torch.isfinite(o5).all()
+        result["extras"] = {"c5": {"metric": f"backbones/sec (L=512, T={T}, bs=128)", "value": 128 / dt5, "unit": "backbones/s",
+                                   "ms_per_timestep": dt5 / T * 1e3, "passes": 1,
+                                   "algorithmic_tflops": 128 / dt5 * flops_per_token(512) * 512 * T / 1e12}}
+        del m5
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(L, T)
+        result["cpu_baseline"] = cpu_baseline(B, L, T, shape)
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
