@@ -20,6 +20,7 @@ CONFIGS = {
     "small": dict(hidden=64, heads=2, ff=128, maxpos=64, B=3, L=37, lens=[37, 33, 8]),
     "mini": dict(hidden=192, heads=6, ff=384, maxpos=128, B=4, L=64, lens=[64, 50, 33, 64]),
     "released": dict(hidden=384, heads=12, ff=768, maxpos=128, B=5, L=128, lens=[128, 128, 77, 50, 1]),
+    "released6": dict(hidden=384, heads=12, ff=768, maxpos=128, B=6, L=128, lens=[128, 128, 77, 50, 1, 100]),
     "ragged": dict(hidden=384, heads=12, ff=768, maxpos=128, B=7, L=101, lens=[101, 50, 99, 100, 64, 3, 77]),
     "long": dict(hidden=64, heads=2, ff=128, maxpos=512, B=2, L=300, lens=[300, 129]),
 }
