@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libfdmi.so")
+LIB_PATH = os.environ.get("FDMI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libfdmi.so")  # FDMI_LIB: A/B builds
 
 FD_OK = 0
 FD_POS = {"absolute": 0, "relative_key": 1, "relative_key_query": 2}

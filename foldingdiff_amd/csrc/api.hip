@@ -185,9 +185,23 @@ void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out,
     }
 }
 
+// Row-image GEMM weights: the same 128-byte blocks, ordered [384-row tile][k-tile][row] so that the 48 KiB a workgroup
+// copies per k-tile are CONSECUTIVE cache lines (spread evenly over the L2 channels; with the row-major order the rows of
+// a k-tile are 4 K bytes apart and hit only some of the channels).  Rows padded to whole tiles with zeros.
+void pack_weight_tiles(const float* W, int N, int K, std::vector<uint16_t>* out, float* scale) {
+  std::vector<uint16_t> rm;
+  pack_split_weight(W, N, K, &rm, scale, 384);
+  const int npad = (N + 383) / 384 * 384, nk = K / 32;
+  out->assign(rm.size(), 0);
+  for (int n = 0; n < npad; ++n)
+    for (int kt = 0; kt < nk; ++kt)
+      memcpy(out->data() + ((((size_t)(n / 384) * nk + kt) * 384) + n % 384) * 64, rm.data() + ((size_t)n * nk + kt) * 64, 128);
+}
+
 int upload_split(fd_model* m, SplitW* dst, const float* W, int N, int K, int row_pad = 128) {
   std::vector<uint16_t> img;
-  pack_split_weight(W, N, K, &img, &dst->scale, row_pad);
+  if (row_pad == 384) pack_weight_tiles(W, N, K, &img, &dst->scale);
+  else pack_split_weight(W, N, K, &img, &dst->scale, row_pad);
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, img.size() * 2));
   m->allocs.push_back(p);
@@ -818,7 +832,7 @@ int img_gemm_hook(int epilogue, const float* A, const float* W, const float* bia
   I_TRY(hk.up(hd, sizeof hd, (void**)&ddims));
   std::vector<uint16_t> img;
   float wscale = 1.f;
-  pack_split_weight(W, N, K, &img, &wscale, 384);
+  pack_weight_tiles(W, N, K, &img, &wscale);
   I_TRY(hk.up(img.data(), img.size() * 2, &dWi));
   const float a_scale = scale_for(max_abs(A, (size_t)M * K));
   launch_f32_to_img(dA, dAi, rows, K, M, a_scale, nullptr);
@@ -1423,7 +1437,7 @@ int fd_test_gemm_time(int device_id, int precision, int M, int N, int K, int rep
     int* ddims;
     std::vector<uint16_t> img;
     float wscale = 1.f;
-    pack_split_weight(hW.data(), N, K, &img, &wscale, 384);
+    pack_weight_tiles(hW.data(), N, K, &img, &wscale);
     T_TRY(hk.up(nullptr, (size_t)rows * K * 4, &dAi));
     T_TRY(hk.up(img.data(), img.size() * 2, &dWi));
     T_TRY(hk.up(nullptr, 1024, &dtrash));

@@ -11,6 +11,7 @@
 // fp32 accumulator (fp16 x fp16 products are exact in fp32; the dropped lo*lo term is 2^-22 relative).
 //
 // What is different from a register-staged split GEMM:
+//  * the weight image is stored [384-row tile][k-tile][row][128 B]: a k-tile's 48 KiB are consecutive cache lines
 //  * BOTH operands already live in HBM as hi|lo row images (activations are written that way by every
 //    producer epilogue), so a k-tile (32 k = one 128-byte block per row) is staged with LDS-DMA
 //    (buffer_load_dwordx4 ... lds): no VGPR round trip, no split arithmetic, no ds_write in the k-loop.
@@ -19,6 +20,7 @@
 //  * 128 (M) x 384 (N) block, 8 waves as 2 (M) x 4 (N), wave tile 64 x 96 = 2 x 3 MFMA tiles (96 accumulators),
 //    18 MFMAs per 10 fragment fetches.  W ring: 2 stages (always L2 hits), A ring: 3 stages (the HBM stream,
 //    issued two k-tiles ahead), ONE workgroup barrier per k-tile, counted s_waitcnt vmcnt (never 0 in the loop).
+//    A ninth wave is the loader: it issues every LDS-DMA piece, the eight compute waves only read fragments and issue MFMAs.
 //  * persistent: one workgroup per CU walks an XCD-aware tile list; the (tile, k-tile) pairs form one
 //    continuous stream, so the next tile's operands are in flight during the epilogue.
 //  * "swapped" MFMA form (D^T = W A^T; all epilogues but EPI_VT): a lane owns ONE token row and 16 columns, so
@@ -35,7 +37,7 @@ namespace gi {
 struct StreamNo { static constexpr bool value = false; };
 struct StreamYes { static constexpr bool value = true; };
 
-constexpr int BM = 128, BN = 384, NTHR = 512;
+constexpr int BM = 128, BN = 384, NTHR = 576;  // 8 compute waves + 1 loader wave
 constexpr int W_STAGE = BN * 128, A_STAGE = BM * 128;           // bytes per k-tile stage
 constexpr int NWS = 2, NAS = 3;
 constexpr int OFF_A = NWS * W_STAGE;                            //  98,304
@@ -72,6 +74,7 @@ __device__ __forceinline__ float gelu_erf(float x) {  // HF "gelu": 0.5 x (1 + e
 // 3 = no fragment reads + no MFMAs (DMA only)
 template <int EPI, bool SWAP, bool PROF, int DBG = 0>
 __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
+  static_assert(DBG == 0, "the ablation builds belonged to the all-waves-issue revision (profiles/r02_gemm_ablation.log)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,94 +102,82 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     }
   }
 
-  // ---- staging: per k-tile 48 W chunks + 16 A chunks of 1 KiB (8 rows x 128 B); wave w issues W chunks
-  // w + 8 i (i < 6) and A chunks w + 8 i (i < 2).  Lane -> (row = 8 chunk + lane / 8, LDS unit = lane % 8),
-  // fetched from source unit (lane % 8) ^ swizzle(row).
-  const int voff = (8 * wid + (lane >> 3)) * rb + (((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) << 4);
-  int iw_ti = 0, iw_kt = 0, ia_ti = 0, ia_kt = 0;  // next stream position to issue (W ring / A ring)
-  int iw_slot = 0, ia_slot = 0;
   auto tile_mn = [&](int ti, int& m0, int& n0) {
     const int tile = first + ti * stride;
     m0 = (tile / tiles_n) * BM;
     n0 = (tile - (tile / tiles_n) * tiles_n) * BN;
   };
-  int iw_n0, ia_m0;  // tile origin of the issue cursors (recomputed only when the cursor enters a new tile)
-  tile_mn(0, ia_m0, iw_n0);
-  // The 8 pieces of a wave (6 W + 2 A) are issued BETWEEN the MFMAs of compute(): all 64 pieces of a k-tile go through
-  // the CU's one vector-memory pipe (64 B/clk: >= 1024 cycles per k-tile), and a wave stalls on issue while that
-  // pipe's queue is full -- back to back after the barrier that was ~1000 cycles per k-tile with the matrix pipe idle
-  // (measured with the PROF stamps), spread out it hides behind the 2304 MFMA cycles.
-  __amdgpu_buffer_rsrc_t rs_w, rs_a;
-  lds_ptr_t dst_w, dst_a;
-  int so_w, so_a;
-  // branch-free (selects only), so that it sits in the same basic block as the MFMAs and the scheduler can sink the
-  // scalar work between them instead of running it on the critical path right after the barrier
-  auto begin_issue = [&]() {
-    rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.W) + (size_t)iw_n0 * rb, 0, BN * rb, 0x00020000);
-    dst_w = (lds_ptr_t)(smem) + iw_slot * W_STAGE + wid * 1024;
-    so_w = iw_kt * 128;
-    iw_slot ^= 1;
-    {
-      const bool more = iw_ti * nk + iw_kt + 1 < G;  // past the end: re-issue the last position (free slot, never read)
-      const bool wrap = more && iw_kt + 1 == nk;
-      const int nti = wrap ? iw_ti + 1 : iw_ti;
-      int mm, nn;
-      tile_mn(nti, mm, nn);
-      iw_kt = wrap ? 0 : (more ? iw_kt + 1 : iw_kt);
-      iw_ti = nti;
-      iw_n0 = nn;
-    }
-    rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.A) + (size_t)ia_m0 * rb, 0, BM * rb, 0x00020000);
-    dst_a = (lds_ptr_t)(smem) + OFF_A + ia_slot * A_STAGE + wid * 1024;
-    so_a = ia_kt * 128;
-    ia_slot = ia_slot == NAS - 1 ? 0 : ia_slot + 1;
-    {
-      const bool more = ia_ti * nk + ia_kt + 1 < G;
-      const bool wrap = more && ia_kt + 1 == nk;
-      const int nti = wrap ? ia_ti + 1 : ia_ti;
-      int mm, nn;
-      tile_mn(nti, mm, nn);
-      ia_kt = wrap ? 0 : (more ? ia_kt + 1 : ia_kt);
-      ia_ti = nti;
-      ia_m0 = mm;
-    }
-  };
-  auto piece = [&](int i) {  // i = 0..5: W pieces, 6..7: A pieces (this order is what the vmcnt bookkeeping assumes)
-    if constexpr (DBG == 1) return;
-    if (i < 6) dma16(rs_w, dst_w + i * 8192, voff, so_w + i * 64 * rb);
-    else dma16(rs_a, dst_a + (i - 6) * 8192, voff, so_a + (i - 6) * 64 * rb);
-  };
-  auto issue_w = [&]() {  // prologue only
-    rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.W) + (size_t)iw_n0 * rb, 0, BN * rb, 0x00020000);
-    dst_w = (lds_ptr_t)(smem) + iw_slot * W_STAGE + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma16(rs_w, dst_w + i * 8192, voff, iw_kt * 128 + i * 64 * rb);
-    iw_slot ^= 1;
-    if (iw_ti * nk + iw_kt + 1 < G) {
-      if (++iw_kt == nk) {
-        iw_kt = 0;
-        ++iw_ti;
-        int mm;
-        tile_mn(iw_ti, mm, iw_n0);
-      }
-    }
-  };
-  auto issue_a = [&]() {  // prologue only
-    rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.A) + (size_t)ia_m0 * rb, 0, BM * rb, 0x00020000);
-    dst_a = (lds_ptr_t)(smem) + OFF_A + ia_slot * A_STAGE + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(rs_a, dst_a + i * 8192, voff, ia_kt * 128 + i * 64 * rb);
-    ia_slot = ia_slot == NAS - 1 ? 0 : ia_slot + 1;
-    if (ia_ti * nk + ia_kt + 1 < G) {
-      if (++ia_kt == nk) {
-        ia_kt = 0;
-        ++ia_ti;
-        int nn;
-        tile_mn(ia_ti, ia_m0, nn);
-      }
-    }
-  };
 
+  // ================================================================ the loader wave
+  // Wave 8 issues every LDS-DMA piece of the workgroup: per k-tile 48 W pieces + 16 A pieces of 1 KiB (8 rows x 128 B;
+  // lane -> row 8 j + lane / 8, LDS unit lane % 8, fetched from source unit (lane % 8) ^ swizzle(row)).  A wave that
+  // issues a piece stalls until the CU's vector-memory path accepts it (the path moves ~20 B/clk/CU out of L2 here and is
+  // busy most of a k-tile); with the pieces spread over the compute waves those stalls sat between their MFMAs (k-loop
+  // 107 us, against 72 us without any DMA and 80 us for the DMA stream alone: profiles/r02_gemm_ablation.log).  Now the
+  // compute waves only read fragments and issue MFMAs, and the copy stream runs beside them at its own pace.
+  //   prologue A(0) W(0) A(1);  iteration g:  [vmcnt(16): W(g), A(g) landed] [barrier g] W(g+1) A(g+2)
+  // The barrier publishes k-tile g to the compute waves and tells the loader that compute(g-1) is over, which frees W slot
+  // (g+1) & 1 and A slot (g+2) % 3.  The compute waves execute the same barriers and nothing else of this protocol.
+  if (wid == 8) {
+    const int swz_even = ((lane & 7) ^ (lane >> 4)) << 4, swz_odd = ((lane & 7) ^ (4 + (lane >> 4))) << 4;  // chunk j even / odd
+    const int vw_e = (lane >> 3) * 128 + swz_even, vw_o = (lane >> 3) * 128 + swz_odd;   // W: [tile][k-tile][row][128 B]
+    const int va_e = (lane >> 3) * rb + swz_even, va_o = (lane >> 3) * rb + swz_odd;     // A: row-major image
+    int w_ti = 0, w_kt = 0, a_ti = 0, a_kt = 0, w_slot = 0, a_slot = 0, w_n0, a_m0;
+    tile_mn(0, a_m0, w_n0);
+    auto issue_w = [&]() {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(p.W) + (size_t)w_n0 * rb, 0, BN * rb, 0x00020000);
+      lds_ptr_t dst = (lds_ptr_t)(smem) + w_slot * W_STAGE;
+      const int so = w_kt * W_STAGE;
+#pragma unroll
+      for (int j = 0; j < 48; ++j) dma16(rs, dst + j * 1024, (j & 1) ? vw_o : vw_e, so + j * 1024);
+      w_slot ^= 1;
+      if (w_ti * nk + w_kt + 1 < G) {  // past the end: re-issue the last position (lands in a free slot, never read)
+        if (++w_kt == nk) {
+          w_kt = 0;
+          ++w_ti;
+          int mm;
+          tile_mn(w_ti, mm, w_n0);
+        }
+      }
+    };
+    auto issue_a = [&]() {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(p.A) + (size_t)a_m0 * rb, 0, BM * rb, 0x00020000);
+      lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + a_slot * A_STAGE;
+      const int so = a_kt * 128;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dma16(rs, dst + j * 1024, (j & 1) ? va_o : va_e, so + j * 8 * rb);
+      a_slot = a_slot == NAS - 1 ? 0 : a_slot + 1;
+      if (a_ti * nk + a_kt + 1 < G) {
+        if (++a_kt == nk) {
+          a_kt = 0;
+          ++a_ti;
+          int nn;
+          tile_mn(a_ti, a_m0, nn);
+        }
+      }
+    };
+    issue_a();
+    issue_w();
+    issue_a();
+    for (int ti = 0; ti < cnt; ++ti) {
+      for (int kt = 0; kt < nk; ++kt) {
+        FD_WAIT_VM(16);
+        barrier_keep_vm();
+        issue_w();
+        issue_a();
+      }
+      if constexpr (EPI == EPI_IMG_LN) {  // the two barriers of the compute waves' LayerNorm reductions
+        barrier_keep_vm();
+        barrier_keep_vm();
+      }
+    }
+    FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
+    return;
+  }
+
+  // ================================================================ the compute waves
   // ---- fragment reads: rows wn*96 + 32 jn + l31 (W) / wm*64 + 32 im + l31 (A); every such row has
   // swizzle (l31 >> 1) & 7, so a lane needs four unit offsets per operand: [k16 step c][plane]
   const int sw = (l31 >> 1) & 7;
@@ -211,8 +202,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   zero_acc();
 
-  // MFMA order: term by term over the six tiles (consecutive MFMAs never share an accumulator).  One DMA piece goes
-  // behind every fourth / fifth MFMA: 4 pieces per k16 step.
+  // MFMA order: term by term over the six tiles (consecutive MFMAs never share an accumulator).
   auto compute = [&](int wslot, int aslot, auto swap_form) {
     constexpr bool SW = decltype(swap_form)::value;
     auto mm = [&](const f16x8& wf, const f16x8& af, f32x16& c) {
@@ -238,35 +228,19 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         al[c][im] = *reinterpret_cast<const f16x8*>(ab + ard[c][1] + im * 4096);
       }
     }
-    begin_issue();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       // hi * hi
       mm(wh[c][0], ah[c][0], acc[0][0]); mm(wh[c][0], ah[c][1], acc[0][1]); mm(wh[c][1], ah[c][0], acc[1][0]); mm(wh[c][1], ah[c][1], acc[1][1]);
-      piece(4 * c + 0);
       mm(wh[c][2], ah[c][0], acc[2][0]); mm(wh[c][2], ah[c][1], acc[2][1]);
       // hi * lo
       mm(wh[c][0], al[c][0], acc[0][0]); mm(wh[c][0], al[c][1], acc[0][1]);
-      piece(4 * c + 1);
       mm(wh[c][1], al[c][0], acc[1][0]); mm(wh[c][1], al[c][1], acc[1][1]); mm(wh[c][2], al[c][0], acc[2][0]); mm(wh[c][2], al[c][1], acc[2][1]);
-      piece(4 * c + 2);
       // lo * hi
       mm(wl[c][0], ah[c][0], acc[0][0]); mm(wl[c][0], ah[c][1], acc[0][1]); mm(wl[c][1], ah[c][0], acc[1][0]); mm(wl[c][1], ah[c][1], acc[1][1]);
-      piece(4 * c + 3);
       mm(wl[c][2], ah[c][0], acc[2][0]); mm(wl[c][2], ah[c][1], acc[2][1]);
     }
-    // Pin the schedule: all twenty fragment reads of the k-tile first (their latency is then paid once, under the other
-    // wave's MFMAs, instead of once per k16 step), then {4 MFMA, 1 VMEM} x 4 + 2 MFMA per k16 step.
-    __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);  // all twenty fragment reads of the k-tile first, then the MFMAs
   };
 
   // ---- epilogues.  SWAP form: lane (l31, half) owns token row  m0 + wm*64 + 32 im + l31  and, per MFMA tile jn,
@@ -471,17 +445,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     return nv;
   };
 
-  // ---- the stream.  In-order vmcnt bookkeeping per wave (DMA pieces: W 6, A 2 per position):
-  //   prologue      A(0) W(0) A(1)
-  //   iteration g   [wait W(g), A(g)] [barrier] W(g+1) A(g+2) compute(g) (+ epilogue stores after the last k-tile)
-  // At the wait of iteration g the younger operations are A(g+1) (2) and, right after an epilogue, that tile's
-  // stores: vmcnt(2) / vmcnt(2 + 8 per stored column block) keeps all of them in flight.  The barrier also tells
-  // every wave that compute(g-1) is over, which frees W slot (g+1) & 1 and A slot (g+2) % 3.
-  issue_a();
-  issue_w();
-  issue_a();
+  // ---- the stream of the compute waves: one barrier per k-tile (the loader's), fragments + MFMAs, the epilogue after a
+  // tile's last k-tile.  Their only vector-memory work is the epilogue's loads and stores; nothing is ever waited for
+  // at the top of the loop.
   int cw = 0, ca = 0;  // slots of the position being computed
-  int nv_prev = -1;    // column blocks stored by the previous tile's epilogue (-1: none yet)
   const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
   unsigned long long* st = PROF ? p.stamps + ((size_t)EPI * 8 + wid) * 64 * 6 : nullptr;
   int slot = 0;
@@ -489,15 +456,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   for (int ti = 0; ti < cnt; ++ti) {
     for (int kt = 0; kt < nk; ++kt) {
       FD_STAMP(0);
-      if constexpr (DBG == 1) {
-        // nothing in flight
-      } else if (kt == 0 && nv_prev > 0) {
-        if (nv_prev == 3) FD_WAIT_VM(2 + 24);
-        else if (nv_prev == 2) FD_WAIT_VM(2 + 16);
-        else FD_WAIT_VM(2 + 8);
-      } else {
-        FD_WAIT_VM(2);
-      }
       FD_STAMP(1);
       barrier_keep_vm();  // (also publishes the EPI_LN parameter image before the first epilogue)
       FD_STAMP(2);
@@ -512,13 +470,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       ca = ca == NAS - 1 ? 0 : ca + 1;
       if (kt + 1 < nk) ++slot;
     }
-    nv_prev = epilogue(ti);
+    (void)epilogue(ti);
     FD_STAMP(5);
     ++slot;
     zero_acc();
   }
 #undef FD_STAMP
-  FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
 static int n_cu_of_current_device() {
@@ -548,19 +505,6 @@ static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
   int grid = n_cu_of_current_device() / 8 * 8;
   if (grid > ntiles_max) grid = (ntiles_max + 7) / 8 * 8;
   if (grid < 8) grid = 8;
-  static const int dbg = [] { const char* e = getenv("FDMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
-  if (dbg >= 1 && dbg <= 3) {
-    if constexpr (EPI == EPI_IMG_QK) {  // ablations are built for the QK projection only
-      const void* f = dbg == 1 ? reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 1>)
-                    : dbg == 2 ? reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 2>)
-                               : reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 3>);
-      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-      if (dbg == 1) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 1>), dim3(grid), dim3(NTHR), SMEM, s, p);
-      else if (dbg == 2) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 2>), dim3(grid), dim3(NTHR), SMEM, s, p);
-      else hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 3>), dim3(grid), dim3(NTHR), SMEM, s, p);
-      return;
-    }
-  }
   if (p.stamps) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, true>), dim3(grid), dim3(NTHR), SMEM, s, p);
   else hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false>), dim3(grid), dim3(NTHR), SMEM, s, p);
 }
