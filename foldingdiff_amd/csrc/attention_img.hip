@@ -70,6 +70,10 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
   unsigned char* Ks = gbase + G::OFF_K;
   unsigned char* Vt = gbase + G::OFF_V;
   float* Rw = reinterpret_cast<float*>(gbase + G::OFF_R) + wq * 32 * RLD;
+  // this wave's skew scratch: LDS byte address for the addtid stores, and the row this lane reads back (query l31 =
+  // 8q + 4h + e lives at register slot 4q + e, half h)
+  const unsigned rw_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)(reinterpret_cast<unsigned char*>(Rw)));
+  const float* Rrow = Rw + ((l31 >> 3) * 4 + (l31 & 3)) * 64 + ((l31 >> 2) & 1) * 32;
   const int H = p.H, nqg = p.NKT;  // query groups == key tiles
   const int nitems = p.B * H * nqg;
   const int gstride = 2 * gridDim.x;
@@ -247,8 +251,28 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], el1, racc, 0, 0, 0);
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[1], eh1, racc, 0, 0, 0);
           }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) Rw[((r & 3) + 8 * (r >> 2) + 4 * half) * RLD + l31] = racc[r];
+          // scratch layout [register r][lane] (R row 8q + 4 half + e of lane-column l31 at r * 256 + lane * 4): the 16 stores
+          // are ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR: 2 LDS cycles instead of 4)
+          {
+            unsigned keep;
+            asm volatile(
+                // (the MFMA results need 12 wait states before a non-MFMA reader: hipcc pads nothing inside an asm statement)
+                "s_nop 7\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 2\n\t"
+                "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
+                "ds_write_addtid_b32 %3 offset:512\n\tds_write_addtid_b32 %4 offset:768\n\t"
+                "ds_write_addtid_b32 %5 offset:1024\n\tds_write_addtid_b32 %6 offset:1280\n\t"
+                "ds_write_addtid_b32 %7 offset:1536\n\tds_write_addtid_b32 %8 offset:1792\n\t"
+                "ds_write_addtid_b32 %9 offset:2048\n\tds_write_addtid_b32 %10 offset:2304\n\t"
+                "ds_write_addtid_b32 %11 offset:2560\n\tds_write_addtid_b32 %12 offset:2816\n\t"
+                "ds_write_addtid_b32 %13 offset:3072\n\tds_write_addtid_b32 %14 offset:3328\n\t"
+                "ds_write_addtid_b32 %15 offset:3584\n\tds_write_addtid_b32 %16 offset:3840\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(racc[0]), "v"(racc[1]), "v"(racc[2]), "v"(racc[3]), "v"(racc[4]), "v"(racc[5]), "v"(racc[6]), "v"(racc[7]),
+                  "v"(racc[8]), "v"(racc[9]), "v"(racc[10]), "v"(racc[11]), "v"(racc[12]), "v"(racc[13]), "v"(racc[14]), "v"(racc[15]),
+                  "s"(rw_lds)
+                : "memory");
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -258,7 +282,7 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            gth[r] = Rw[l31 * RLD + ((l31 - kl + 31) & 31)];
+            gth[r] = Rrow[(l31 - kl + 31) & 31];
           }
           if (qq < T) {
 #pragma unroll
