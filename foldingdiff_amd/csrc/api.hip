@@ -387,7 +387,7 @@ int ensure_ws(fd_model* m, int B, int L) {
     HIP_TRY(alz((void**)&w.cimg, cap * d * 4));
     HIP_TRY(alz((void**)&w.gimg, cap * gmax * 4));
     HIP_TRY(alz((void**)&w.qbuf, BH * w.LTOT * 128));
-    HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 144));
+    HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.vbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.trash, 1024));
     HIP_TRY(alz((void**)&w.rowinfo, cap * sizeof(int2)));
@@ -1549,7 +1549,7 @@ int fd_debug_read(fd_model* m, const char* name, float* out, int64_t n_floats) {
   else if (nm == "g") rc = img(w.gimg, c.d_ff, lw.s_g);
   else if (nm == "g_head") rc = img(w.gimg, c.d_model, m->s_hg);
   else if (nm == "q") rc = qkv(w.qbuf, 128, 0, lw.s_q);
-  else if (nm == "k") rc = qkv(w.kbuf, 144, 0, lw.s_k);
+  else if (nm == "k") rc = qkv(w.kbuf, 128, 2, lw.s_k);
   else if (nm == "v") rc = qkv(w.vbuf, 0, 1, lw.s_v);
   else if (nm == "stamps") {
     need = 5 * 8 * 64 * 6 + 4 * 64 * 8;

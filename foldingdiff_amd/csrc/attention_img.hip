@@ -4,7 +4,7 @@
 //
 // Inputs are what the QK / V^T GEMM epilogues wrote, already split and already in the LDS layout:
 //     q   [b][h][LTOT rows][128 B]   hi d0-31 | lo d0-31
-//     k   [b][h][LTOT rows][144 B]   hi | lo | 16 B pad      (conflict-free 16-byte operand fetches)
+//     k   [b][h][LTOT rows][128 B]   the same, 16-byte unit u of row r stored at u ^ ((r >> 1) & 7)  (conflict-free fetches)
 //     vt  [b][h][32-key block][32 d][128 B]    V transposed: hi keys | lo keys as sixteen 8-byte units, unit u stored
 //                                               at u ^ ((d >> 1) & 15)  (conflict-free 8-byte operand fetches)
 // so filling LDS is a linear LDS-DMA copy: no VGPR round trip, no split arithmetic, no ds_write.
@@ -27,7 +27,6 @@
 namespace fdmi {
 namespace ai {
 
-constexpr int KROW = 144;
 constexpr int RLD = 36;
 constexpr float PS = 1024.0f;  // probabilities are <= 1
 constexpr float kLog2e = 1.44269504088896341f;
@@ -40,12 +39,12 @@ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 template <int T, bool ELDS>
 struct Geo {
   static constexpr int LP = 32 * T;
-  static constexpr int K_BYTES = LP * KROW, V_BYTES = LP * 128;
+  static constexpr int K_BYTES = LP * 128, V_BYTES = LP * 128;
   static constexpr int KC = ceil_div(K_BYTES, 1024), VC = ceil_div(V_BYTES, 1024);
   static constexpr int KW = ceil_div(KC, 4), VW = ceil_div(VC, 4);  // DMA pieces per wave (4 waves per group)
   static constexpr int E_BYTES = ELDS ? 32 * 1024 : 0;              // distance table image, 255 rows x 128 B (maxpos <= 128)
   static constexpr int OFF_K = 0, OFF_V = OFF_K + KW * 4 * 1024, OFF_R = OFF_V + VW * 4 * 1024;
-  static constexpr int G_REL = OFF_R + 4 * 32 * RLD * 4, G_ABS = OFF_R;  // bytes per group
+  static constexpr int G_REL = OFF_R + 4 * 32 * 32 * 4, G_ABS = OFF_R;  // bytes per group (skew scratch: 4 KiB per wave)
 };
 
 // Two 4-wave groups per workgroup (8 waves, one workgroup per CU), each group walking its own stream of
@@ -55,8 +54,8 @@ struct Geo {
 // (loads retire in order: a table fetch from L2 behind a V copy used to stall the band phase until V had landed).
 // Q comes straight from global memory into registers, one item ahead.
 // SAFE: every wait is vmcnt(0) (debug aid for the counted-wait bookkeeping)
-template <int T, bool REL, bool ELDS, bool SAFE, bool PROF = false>
-__global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
+template <int T, bool REL, bool ELDS, int NG, bool SAFE, bool PROF = false>
+__global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   using G = Geo<T, ELDS>;
   constexpr int LP = G::LP;
   constexpr int GSZ = REL ? G::G_REL : G::G_ABS;
@@ -69,14 +68,14 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
   unsigned char* gbase = smem + G::E_BYTES + grp * GSZ;
   unsigned char* Ks = gbase + G::OFF_K;
   unsigned char* Vt = gbase + G::OFF_V;
-  float* Rw = reinterpret_cast<float*>(gbase + G::OFF_R) + wq * 32 * RLD;
+  float* Rw = reinterpret_cast<float*>(gbase + G::OFF_R) + wq * 32 * 32;
   // this wave's skew scratch: LDS byte address for the addtid stores, and the row this lane reads back (query l31 =
   // 8q + 4h + e lives at register slot 4q + e, half h)
   const unsigned rw_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)(reinterpret_cast<unsigned char*>(Rw)));
   const float* Rrow = Rw + ((l31 >> 3) * 4 + (l31 & 3)) * 64 + ((l31 >> 2) & 1) * 32;
   const int H = p.H, nqg = p.NKT;  // query groups == key tiles
   const int nitems = p.B * H * nqg;
-  const int gstride = 2 * gridDim.x;
+  const int gstride = NG * gridDim.x;
 
   // ---- the stream of (item, key tile) positions of this group: items 2 blockIdx + grp, + 2 gridDim, ...
   struct Pos { int item, kt, b, h, qg, len, nkt; };
@@ -98,13 +97,13 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
   // positions of a group's stream (both groups loop to the longer one: the barriers are shared)
   auto stream_len = [&](int g) {
     int n = 0;
-    for (int it = 2 * blockIdx.x + g; it < nitems; it += gstride) {
+    for (int it = NG * blockIdx.x + g; it < nitems; it += gstride) {
       const int bb = it / (nqg * H);
       n += (p.lens[bb] + LP - 1) / LP;
     }
     return n;
   };
-  const int my_len = stream_len(grp), other_len = stream_len(grp ^ 1);
+  const int my_len = stream_len(grp), other_len = NG == 2 ? stream_len(grp ^ 1) : 0;
   const int niter = my_len > other_len ? my_len : other_len;
   const bool has_work = my_len > 0;
 
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
   };
   auto issue_k = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
-    copy(p.kbuf + (bh * p.LTOT + (size_t)s.kt * LP) * KROW, G::K_BYTES, G::KC, G::KW, Ks);
+    copy(p.kbuf + (bh * p.LTOT + (size_t)s.kt * LP) * 128, G::K_BYTES, G::KC, G::KW, Ks);
   };
   auto issue_v = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
   };
 
   Pos cur, nxt;
-  load_item(cur, 2 * blockIdx.x + grp);
+  load_item(cur, NG * blockIdx.x + grp);
   u32x4 qn[4];
   if constexpr (REL && ELDS) {
     // distance table -> LDS once per workgroup: 32 pieces of 8 rows, unit u of row m stored at u ^ ((m >> 1) & 7)
@@ -142,8 +141,8 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.demb)), 0, nrow_e * 128, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wid + 8 * i;  // rows 8 piece .. 8 piece + 7
+    for (int i = 0; i < 8 / NG; ++i) {
+      const int piece = wid + 4 * NG * i;  // rows 8 piece .. 8 piece + 7
       const int row = 8 * piece + (lane >> 3);
       dma16(rs, (lds_ptr_t)(Es) + piece * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4), 0);
     }
@@ -205,11 +204,12 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
       for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-        const unsigned char* row = Ks + (size_t)(32 * t + l31) * KROW;
+        const unsigned char* row = Ks + (size_t)(32 * t + l31) * 128;   // unit u of key row r at u ^ ((r >> 1) & 7)
+        const int ksz = (l31 >> 1) & 7;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const f16x8 kh = *reinterpret_cast<const f16x8*>(row + 32 * c + 16 * half);
-          const f16x8 kl = *reinterpret_cast<const f16x8*>(row + 64 + 32 * c + 16 * half);
+          const f16x8 kh = *reinterpret_cast<const f16x8*>(row + (((2 * c + half) ^ ksz) << 4));
+          const f16x8 kl = *reinterpret_cast<const f16x8*>(row + (((4 + 2 * c + half) ^ ksz) << 4));
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
@@ -423,10 +423,13 @@ __global__ __launch_bounds__(512) void attn_img_kernel(AttnImgArgs p) {
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
-template <int T, bool REL, bool ELDS>
-static void launch(const AttnImgArgs& p, hipStream_t s) {
+// NG = groups (item streams) per workgroup = 2: one 8-wave workgroup per CU, both groups behind the same barriers, one
+// copy of the distance table.  (NG = 1 -- independent 4-wave workgroups with a table copy each, exactly 80 KiB -- was
+// measured at 179 vs 131 us: two such workgroups do not become co-resident, profiles/r02_attention_notes.log.)
+template <int T, bool REL, bool ELDS, int NG>
+static void launch_ng(const AttnImgArgs& p, hipStream_t s) {
   using G = Geo<T, ELDS>;
-  constexpr int smem = G::E_BYTES + 2 * (REL ? G::G_REL : G::G_ABS);
+  constexpr int smem = G::E_BYTES + NG * (REL ? G::G_REL : G::G_ABS);
   static const bool safe = [] { const char* e = getenv("FDMI_ATTN_SAFE"); return e && atoi(e) != 0; }();
   static bool attr_set[64] = {false};
   static int n_cu[64] = {0};
@@ -434,22 +437,27 @@ static void launch(const AttnImgArgs& p, hipStream_t s) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipDeviceProp_t prop;
     n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     attr_set[dev] = true;
   }
   const int nitems = p.B * p.H * p.NKT;
-  int grid = n_cu[dev];  // one 8-wave workgroup (two item streams) per CU
-  if (grid > (nitems + 1) / 2) grid = (nitems + 1) / 2;
-  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, false, true>), dim3(grid), dim3(512), smem, s, p);
-  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, true>), dim3(grid), dim3(512), smem, s, p);
-  else hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, false>), dim3(grid), dim3(512), smem, s, p);
+  int grid = n_cu[dev] * (NG == 1 ? 2 : 1);  // 8 waves per CU either way
+  if (grid > (nitems + NG - 1) / NG) grid = (nitems + NG - 1) / NG;
+  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, false, true>), dim3(grid), dim3(256 * NG), smem, s, p);
+  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, true>), dim3(grid), dim3(256 * NG), smem, s, p);
+  else hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, false>), dim3(grid), dim3(256 * NG), smem, s, p);
+}
+
+template <int T, bool REL, bool ELDS>
+static void launch(const AttnImgArgs& p, hipStream_t s) {
+  launch_ng<T, REL, ELDS, 2>(p, s);
 }
 
 }  // namespace ai

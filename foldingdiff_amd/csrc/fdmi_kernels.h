@@ -116,7 +116,7 @@ struct GemmImgArgs {
   const unsigned char* resid;  // image [rows128][N/32]   EPI_IMG_LN
   unsigned char* out;          // image [rows128][N/32]   EPI_IMG_GELU / EPI_IMG_LN
   unsigned char* qbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK
-  unsigned char* kbuf;         // [B][H][LTOT][144 B]     EPI_IMG_QK
+  unsigned char* kbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK (unit u of row l at u ^ ((l >> 1) & 7))
   unsigned char* vbuf;         // [B][H][LTOT / 32][32 d][128 B]  EPI_IMG_VT (V transposed, swizzled: gemm_img.hip)
   unsigned char* trash;        // >= 256 B scratch line for the stores of padding rows
   const int2* rowinfo;

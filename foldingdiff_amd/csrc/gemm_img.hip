@@ -2,7 +2,7 @@
 //
 //   C[M,N] = A[M,K] * W[N,K]^T + bias[N]   then one of four epilogues
 //     EPI_QK    q | k of HF BertSelfAttention (transformers 4.11.3, called from foldingdiff/modelling.py:473-480)
-//               scattered per (sequence, head) in the layouts the attention kernel DMA-copies into LDS
+//               scattered per (sequence, head) as 128-byte rows (k: units swizzled) that the attention kernel copies into LDS
 //     EPI_VT    v, written transposed per (sequence, head, 32-key block): [d][hi keys | lo keys], swizzled
 //     EPI_GELU  BertIntermediate.dense / AnglesPredictor.dense1 + exact-erf GELU (modelling.py:195-196, :203-205)
 //     EPI_LN    BertSelfOutput / BertOutput: LayerNorm(dense(x) + residual)
@@ -295,8 +295,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * q + 4 * half);
         const float sc = isk ? p.k_scale : p.q_scale;
-        const size_t pitch = isk ? (size_t)p.LTOT * 144 : (size_t)p.LTOT * 128;
-        const size_t rbytes = isk ? 144 : 128;
+        const size_t pitch = (size_t)p.LTOT * 128;
         unsigned char* basep = isk ? p.kbuf : p.qbuf;
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
@@ -309,8 +308,9 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3], os, b4[q].w);
           }
           const bool ok = ri[im].x >= 0;
-          unsigned char* dst = ok ? basep + ((size_t)ri[im].x * H + h) * pitch + (size_t)ri[im].y * rbytes : p.trash;
-          store_block(dst, o, sc, half, true);
+          unsigned char* dst = ok ? basep + ((size_t)ri[im].x * H + h) * pitch + (size_t)ri[im].y * 128 : p.trash;
+          // k rows carry the LDS bank swizzle of the attention kernel (unit ^ ((position >> 1) & 7)); q rows are plain
+          store_block_swz(dst, o, sc, half, (isk && ok) ? ((ri[im].y >> 1) & 7) : 0);
         }
       }
     } else if constexpr (EPI == EPI_IMG_VT) {

@@ -107,6 +107,19 @@ __device__ __forceinline__ void store_block(unsigned char* blk, const float (&v)
   }
 }
 
+// The same with the block's eight 16-byte units permuted: unit u is stored at u ^ sz (sz = (row >> 1) & 7 for the k rows,
+// which the attention kernel copies linearly into LDS and reads with 16-byte operand fetches: conflict free without
+// padding the rows to 144 bytes)
+__device__ __forceinline__ void store_block_swz(unsigned char* blk, const float (&v)[16], float s, int half, int sz) {
+  u32x4 h0, h1, l0, l1;
+  pack_block(v, s, h0, h1, l0, l1);
+  u32x4* u = reinterpret_cast<u32x4*>(blk);
+  u[(2 * half) ^ sz] = h0;
+  u[(2 * half + 1) ^ sz] = h1;
+  u[(4 + 2 * half) ^ sz] = l0;
+  u[(5 + 2 * half) ^ sz] = l1;
+}
+
 __device__ __forceinline__ float h2f_lo(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
 __device__ __forceinline__ float h2f_hi(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
 

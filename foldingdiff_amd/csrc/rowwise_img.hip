@@ -345,15 +345,16 @@ __global__ void qkv_unpack_kernel(const unsigned char* __restrict__ src, float* 
     const long long bh = row / LTOT;
     const int l = (int)(row - bh * LTOT);
     const _Float16 *hp, *lp;
-    if (is_vt) {  // [bh][l / 32][d][128 B], 8-byte unit u at position u ^ ((d >> 1) & 15)
+    if (is_vt == 1) {  // [bh][l / 32][d][128 B], 8-byte unit u at position u ^ ((d >> 1) & 15)
       const int kb = l >> 5, kl = l & 31, sz = (dd >> 1) & 15;
       const unsigned char* r = src + (((bh * (LTOT >> 5) + kb) * 32) + dd) * (size_t)128;
       hp = reinterpret_cast<const _Float16*>(r + (((kl >> 2) ^ sz) << 3)) + (kl & 3);
       lp = reinterpret_cast<const _Float16*>(r + (((8 + (kl >> 2)) ^ sz) << 3)) + (kl & 3);
-    } else {
+    } else {  // is_vt == 2: k rows, 16-byte unit u stored at u ^ ((l >> 1) & 7)
       const unsigned char* r = src + row * (size_t)rowbytes;
-      hp = reinterpret_cast<const _Float16*>(r) + dd;
-      lp = reinterpret_cast<const _Float16*>(r + 64) + dd;
+      const int sz = is_vt == 2 ? (l >> 1) & 7 : 0;
+      hp = reinterpret_cast<const _Float16*>(r + (((dd >> 3) ^ sz) << 4)) + (dd & 7);
+      lp = reinterpret_cast<const _Float16*>(r + (((4 + (dd >> 3)) ^ sz) << 4)) + (dd & 7);
     }
     dst[i] = ((float)*hp + (float)*lp) * inv_s;
   }
