@@ -57,7 +57,7 @@ def flops_per_token(L, d=384, ff=768, layers=12, F=6):
     return layers * (8 * d * d + 4 * d * ff + 6 * L * d) + 2 * F * d + 2 * d * d + 2 * d * F
 
 
-def cpu_baseline(B, L, T, shape, steps=10):
+def cpu_baseline(B, L, T, shape, steps=3):
     """Reference CPU path (oracle port of foldingdiff/sampling.py p_sample_loop + the restated BertForDiffusion), host
     cores of this box, on a bounded sample of the SAME workload: `steps` consecutive reverse steps at the
     full batch, extrapolated to T steps (steps are homogeneous: same kernels, same shapes, t only indexes tables)."""
@@ -226,7 +226,8 @@ def main():
     mfma_mult = 3.0 if model.precision == "f16x3" else 1.0
     ms_step = elapsed / args.steps / T * 1e3
     dom = kernels.get("gemm_qkv")
-    pinfo = PRECISION_INFO[model.precision]
+    pinfo_key = model.precision  # (the exact-fp32 pass below switches the model)
+    pinfo = PRECISION_INFO[pinfo_key]
     traffic = None
     try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (separate runs, see profiles/)
         with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
@@ -293,7 +294,7 @@ def main():
     if world == 1 and args.config == "c2" and not args.no_c5_extra:
         # BASELINE config C5 (L = 512 long-chain stress, batch 128, max_position_embeddings = 512): one timed pass
         m5 = modelling.BertForDiffusionBase(modelling.BertConfig(**dict(RELEASED, max_position_embeddings=512)), [True] * 6).to(dev)
-        m5.set_precision(model.precision)
+        m5.set_precision(pinfo_key)
         m5.prepare(betas)
         x5 = ds.sample_noise(torch.zeros(128, 512, 6)).contiguous().to(dev)
         l5 = torch.full((128,), 512, dtype=torch.int32, device=dev)
