@@ -34,8 +34,8 @@ from foldingdiff_amd import modelling, sampling  # noqa: E402
 from foldingdiff_amd.angles_and_coords import write_preds_pdb_folder  # noqa: E402
 from foldingdiff_amd.datasets import AnglesEmptyDataset, NoisedAnglesDataset  # noqa: E402
 
-# the reference's default seed expression (bin/sample.py:34-37) evaluates to this
-SEED = int(float.fromhex("54616977616e20697320616e20696e646570656e64656e7420636f756e747279") % 10000)
+# the value the reference's default seed expression (bin/sample.py:34-37) evaluates to
+SEED = 7344
 
 
 def build_datasets(model_dir: Path) -> NoisedAnglesDataset:

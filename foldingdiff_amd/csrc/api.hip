@@ -125,7 +125,6 @@ struct fd_model {
   // options
   int fuse_ln = -1;  // -1 auto: LN-fused GEMMs with fp16x3 (measured 9.37 vs 10.15 ms/step), not with fp32 (slower there)
   int use_graph = 1;
-  int attn_f16 = 1;  // with FD_PREC_F16X3: attention on the fp16x3 kernel (0: keep the fp32-MFMA one)
   unsigned long long* stamps = nullptr;  // debug cycle stamps (FDMI_STAMPS=1): gemm [5][8][64][6] then attention [4][64][8]
   int debug_stop = 0;  // row-image path: stop a step after this many launches (debug dumps; 0 = off)
   int debug_layer = 0; // layer whose scales fd_debug_read uses
@@ -1093,10 +1092,6 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   else if (n == "varlen") m->varlen = value ? 1 : 0;
   else if (n == "debug_stop") m->debug_stop = value;
   else if (n == "debug_layer") m->debug_layer = value;
-  else if (n == "attn_f16") {
-    m->attn_f16 = value ? 1 : 0;
-    m->ws.graph_fuse_ln = -2;  // force a re-capture
-  }
   else return fail(FD_E_INVALID, "unknown option '%s'", name);
   return FD_OK;
 }

@@ -9,11 +9,12 @@
 //                                               at u ^ ((d >> 1) & 15)  (conflict-free 8-byte operand fetches)
 // so filling LDS is a linear LDS-DMA copy: no VGPR round trip, no split arithmetic, no ds_write.
 //
-// A 4-wave workgroup is persistent over (sequence, head, query group) items and treats the (item, key tile)
-// pairs as one stream with split-phase prefetch (one K buffer, one V buffer):
-//     [A] K(p), Q(p) landed | S^T = K Q^T and the relative-key band  | [B] K region free -> DMA K(p+1), Q(p+1)
+// One 8-wave workgroup per CU, persistent; its waves form two 4-wave groups, each walking its own stream of
+// (sequence, head, query group) x key-tile positions with split-phase prefetch (per group one K buffer, one V buffer):
+//     [A] K(p) landed       | S^T = K Q^T and the relative-key band  | [B] K region free -> DMA K(p+1)
 //         softmax                                                    | [C] V(p) landed
 //         O^T += V^T P^T                                             | [D] V region free -> DMA V(p+1)
+// Q goes from global memory straight to registers, one item ahead.
 // so every copy has a whole compute phase to land.  Waits are counted (s_waitcnt vmcnt(N)), never 0 in the loop.
 // A wave owns one 32-query row block; S^T (keys x queries) puts a query's scores in one lane pair, so softmax is
 // in-register and P is already the B operand of the PV MFMA; the relative_key term is dense 32x32 tiles
@@ -27,7 +28,6 @@
 namespace fdmi {
 namespace ai {
 
-constexpr int RLD = 36;
 constexpr float PS = 1024.0f;  // probabilities are <= 1
 constexpr float kLog2e = 1.44269504088896341f;
 constexpr float kInvSqrtD = 0.17677669529663687f;  // 1 / sqrt(32)

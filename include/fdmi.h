@@ -108,18 +108,17 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
 void fd_destroy(fd_model* m);
 
 /* Runtime switches:
- *   "fuse_ln"    1: residual + LayerNorm run in the epilogue of the attention-output and
- *                FFN-down GEMMs (shapes without a fused instantiation fall back); 0: separate
- *                LayerNorm kernel (same arithmetic); -1 (default): 1 with FD_PREC_F16X3, 0 with
- *                FD_PREC_F32 (what is fastest on MI355X).
+ *   "fuse_ln"    FD_PREC_F32 only (FD_PREC_F16X3 always fuses): 1: residual + LayerNorm run in the epilogue of
+ *                the attention-output and FFN-down GEMMs (shapes without a fused instantiation fall back);
+ *                0 / -1 (default): separate LayerNorm kernel (same arithmetic, faster in that mode on MI355X).
  *   "use_graph"  1 (default): the per-step kernel sequence is replayed from a hipGraph;
  *                0: eager launches.
- *   "attn_f16"   with FD_PREC_F16X3 only -- 1 (default): attention contractions on the fp16x3
- *                kernel too; 0: keep the exact-fp32 attention kernel.
  *   "varlen"     fd_sample / fd_sample_dev with FD_PREC_F16X3: 1 = positions >= lens[b] are not computed at all
  *                (the reference computes them and sampling.sample cuts them away, sampling.py:56-58, :201-203);
  *                positions < lens[b] are bit-identical either way.  Padded positions of `out` then keep x_init.
- *                0 (default): every position evolves as in the reference's p_sample_loop. */
+ *                0 (default): every position evolves as in the reference's p_sample_loop.
+ *   "debug_stop" n > 0: a step returns after its first n launches (FD_PREC_F16X3; stage-by-stage comparison with
+ *                fd_debug_read, scripts/debug_img.py); "debug_layer": which encoder layer fd_debug_read sees. */
 int fd_set_option(fd_model* m, const char* name, int value);
 
 /* ---- parity hooks ---- */
