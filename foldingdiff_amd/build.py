@@ -1,7 +1,7 @@
 """
 Build libfdmi.so (the gfx950 HIP kernels + C ABI) in-tree with hipcc.
 
-    python -m foldingdiff_amd.build [--force]
+    python -m foldingdiff_amd.build [--force] [variant DEFINE[=VALUE] ...]
 
 hipcc cross-compiles for gfx950 without a GPU present.  The shared object lands in
 foldingdiff_amd/_lib/ (git-ignored, shipped to the GPU box with the tree).
@@ -38,11 +38,15 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link libfdmi.so.  Returns its path."""
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+    """Compile every HIP source for gfx950 and link libfdmi.so.  Returns its path.
+    ``variant`` + ``defines``: an experiment build with extra -D flags in _lib/<variant>/libfdmi.so, selected at run
+    time with FDMI_LIB=<path> (same-box A/B measurements; the default library is untouched)."""
     hipcc = find_hipcc()
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    lib_dir = os.path.join(LIB_DIR, variant) if variant else LIB_DIR
+    lib_path = os.path.join(lib_dir, "libfdmi.so")
+    obj_dir = os.path.join(lib_dir, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     jobs = []
     objs = []
@@ -51,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         op = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + HEADERS):
-            jobs.append([hipcc] + CXXFLAGS + ["-c", sp, "-o", op])
+            jobs.append([hipcc] + CXXFLAGS + [f"-D{d}" for d in defines] + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -63,11 +67,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB_PATH, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
-    return LIB_PATH
+    if force or jobs or _stale(lib_path, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", lib_path])
+    return lib_path
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True)
+    args = [a for a in sys.argv[1:] if a != "--force"]   # [variant [DEFINE[=VALUE] ...]]
+    p = build(force="--force" in sys.argv, verbose=True, variant=args[0] if args else "", defines=args[1:])
     print(p)

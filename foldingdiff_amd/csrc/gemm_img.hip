@@ -37,7 +37,11 @@ namespace gi {
 struct StreamNo { static constexpr bool value = false; };
 struct StreamYes { static constexpr bool value = true; };
 
-constexpr int BM = 128, BN = 384, NTHR = 576;  // 8 compute waves + 1 loader wave
+#ifndef FDMI_NL
+#define FDMI_NL 2
+#endif
+constexpr int NL = FDMI_NL;                                      // loader waves (1, 2 or 4)
+constexpr int BM = 128, BN = 384, NTHR = 64 * (8 + NL);         // 8 compute waves + NL loader waves
 constexpr int W_STAGE = BN * 128, A_STAGE = BM * 128;           // bytes per k-tile stage
 constexpr int NWS = 2, NAS = 3;
 constexpr int OFF_A = NWS * W_STAGE;                            //  98,304
@@ -68,8 +72,8 @@ __device__ __forceinline__ float gelu_erf(float x) {  // HF "gelu": 0.5 x (1 + e
 }
 
 // PROF: workgroup 0 records s_memtime stamps of its waves (debug instrumentation, FDMI_STAMPS=1):
-//   stamps[EPI][wave][slot][6] = {loop top, after the vmcnt wait, after the barrier, after the DMA issue, after compute,
-//   after the epilogue (last k-tile of a tile only)}
+//   stamps[EPI][wave][slot][6] = {k-tile top, after MFMA group 5, after the barrier of the next position, after issuing its
+//   first fragment reads, after group 6, after the epilogue (last k-tile of a tile only)}
 // DBG (ablation builds, FDMI_GEMM_DBG, wrong results by design): 1 = no DMA pieces inside the k-loop, 2 = no MFMAs,
 // 3 = no fragment reads + no MFMAs (DMA only)
 template <int EPI, bool SWAP, bool PROF, int DBG = 0>
@@ -91,6 +95,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   const int cnt = first < thi ? (thi - first + stride - 1) / stride : 0;
   if (cnt == 0) return;
   const int G = cnt * nk;  // stream positions
+  if (p.stagger > 0) {  // experiment: de-phase the workgroups' store bursts
+    const long long wait = (long long)((blockIdx.x >> 3) & 3) * p.stagger, t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
 
   if constexpr (EPI == EPI_IMG_LN) {
     float* par = reinterpret_cast<float*>(smem + OFF_PAR);
@@ -118,10 +126,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   //   prologue A(0) W(0) A(1);  iteration g:  [vmcnt(16): W(g), A(g) landed] [barrier g] W(g+1) A(g+2)
   // The barrier publishes k-tile g to the compute waves and tells the loader that compute(g-1) is over, which frees W slot
   // (g+1) & 1 and A slot (g+2) % 3.  The compute waves execute the same barriers and nothing else of this protocol.
-  if (wid == 8) {
+  if (wid >= 8) {
+    const int li = wid - 8;  // pieces j = li, li + NL, ...: all of one parity
     const int swz_even = ((lane & 7) ^ (lane >> 4)) << 4, swz_odd = ((lane & 7) ^ (4 + (lane >> 4))) << 4;  // chunk j even / odd
     const int vw_e = (lane >> 3) * 128 + swz_even, vw_o = (lane >> 3) * 128 + swz_odd;   // W: [tile][k-tile][row][128 B]
     const int va_e = (lane >> 3) * rb + swz_even, va_o = (lane >> 3) * rb + swz_odd;     // A: row-major image
+    const int vw_l = (li & 1) ? vw_o : vw_e, va_l = (li & 1) ? va_o : va_e;  // even NL: a loader's pieces share one parity
     int w_ti = 0, w_kt = 0, a_ti = 0, a_kt = 0, w_slot = 0, a_slot = 0, w_n0, a_m0;
     tile_mn(0, a_m0, w_n0);
     auto issue_w = [&]() {
@@ -130,7 +140,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       lds_ptr_t dst = (lds_ptr_t)(smem) + w_slot * W_STAGE;
       const int so = w_kt * W_STAGE;
 #pragma unroll
-      for (int j = 0; j < 48; ++j) dma16(rs, dst + j * 1024, (j & 1) ? vw_o : vw_e, so + j * 1024);
+      for (int i = 0; i < 48 / NL; ++i) {
+        const int j = li + i * NL;
+        dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? vw_o : vw_e) : vw_l, so + j * 1024);
+      }
       w_slot ^= 1;
       if (w_ti * nk + w_kt + 1 < G) {  // past the end: re-issue the last position (lands in a free slot, never read)
         if (++w_kt == nk) {
@@ -147,7 +160,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + a_slot * A_STAGE;
       const int so = a_kt * 128;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) dma16(rs, dst + j * 1024, (j & 1) ? va_o : va_e, so + j * 8 * rb);
+      for (int i = 0; i < 16 / NL; ++i) {
+        const int j = li + i * NL;
+        dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + j * 8 * rb);
+      }
       a_slot = a_slot == NAS - 1 ? 0 : a_slot + 1;
       if (a_ti * nk + a_kt + 1 < G) {
         if (++a_kt == nk) {
@@ -161,17 +177,24 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     issue_a();
     issue_w();
     issue_a();
-    for (int ti = 0; ti < cnt; ++ti) {
-      for (int kt = 0; kt < nk; ++kt) {
-        FD_WAIT_VM(16);
-        barrier_keep_vm();
-        issue_w();
-        issue_a();
+    // The compute waves pass barrier g + 1 BEFORE the last MFMA group of position g (they prefetch the first fragments of
+    // g + 1 behind it), so the two barriers of a LayerNorm epilogue follow the barrier of the next tile's first position.
+    for (int g = 0, kt = 0; g < G; ++g) {
+      FD_WAIT_VM(16 / NL);
+      barrier_keep_vm();
+      issue_w();
+      issue_a();
+      if constexpr (EPI == EPI_IMG_LN) {
+        if (g > 0 && kt == 0) {
+          barrier_keep_vm();
+          barrier_keep_vm();
+        }
       }
-      if constexpr (EPI == EPI_IMG_LN) {  // the two barriers of the compute waves' LayerNorm reductions
-        barrier_keep_vm();
-        barrier_keep_vm();
-      }
+      if (++kt == nk) kt = 0;
+    }
+    if constexpr (EPI == EPI_IMG_LN) {
+      barrier_keep_vm();
+      barrier_keep_vm();
     }
     FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
     return;
@@ -180,16 +203,14 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // ================================================================ the compute waves
   // ---- fragment reads: rows wn*96 + 32 jn + l31 (W) / wm*64 + 32 im + l31 (A); every such row has
   // swizzle (l31 >> 1) & 7, so a lane needs four unit offsets per operand: [k16 step c][plane]
+  // (one set of per-lane offsets serves both operands: the wave's row bases are wave-uniform and ride in the slot base)
   const int sw = (l31 >> 1) & 7;
-  int wrd[2][2], ard[2][2];
+  int rd[2][2];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      const int u = ((2 * c + half + 4 * pl) ^ sw) << 4;
-      wrd[c][pl] = (wn * 96 + l31) * 128 + u;
-      ard[c][pl] = OFF_A + (wm * 64 + l31) * 128 + u;
-    }
+    for (int pl = 0; pl < 2; ++pl) rd[c][pl] = l31 * 128 + (((2 * c + half + 4 * pl) ^ sw) << 4);  // ([0][0]: see first_fragments)
+  const int wbase = wn * 96 * 128, abase = OFF_A + wm * 64 * 128;
 
   f32x16 acc[3][2];  // [jn][im]
   auto zero_acc = [&]() {
@@ -202,45 +223,25 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   zero_acc();
 
-  // MFMA order: term by term over the six tiles (consecutive MFMAs never share an accumulator).
-  auto compute = [&](int wslot, int aslot, auto swap_form) {
-    constexpr bool SW = decltype(swap_form)::value;
-    auto mm = [&](const f16x8& wf, const f16x8& af, f32x16& c) {
-      if constexpr (DBG >= 2) {
-        if constexpr (DBG == 2) asm volatile("" ::"v"(wf), "v"(af));
-        return;
-      }
-      c = SW ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, c, 0, 0, 0);
-    };
-    const unsigned char* wb = smem + wslot * W_STAGE;
-    const unsigned char* ab = smem + aslot * A_STAGE;
-    f16x8 wh[2][3], wl[2][3], ah[2][2], al[2][2];  // [k16 step][tile]
+  // One k-tile = six groups of six MFMAs (k16 step c: wh ah | wh al | wl ah; consecutive MFMAs never share an accumulator).
+  // The operands of a group are fetched while the previous group runs, and the barrier of the NEXT position sits before the
+  // last group, so the first fragments of the next k-tile are on their way while this one finishes: the matrix pipe
+  // never waits for a whole fragment set behind a barrier.
+  auto mm6 = [&](const f16x8 (&wf)[3], const f16x8 (&af)[2]) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int jn = 0; jn < 3; ++jn)
 #pragma unroll
-      for (int jn = 0; jn < 3; ++jn) {
-        wh[c][jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][0] + jn * 4096);
-        wl[c][jn] = *reinterpret_cast<const f16x8*>(wb + wrd[c][1] + jn * 4096);
-      }
+      for (int im = 0; im < 2; ++im)
+        acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[jn], af[im], acc[jn][im], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], wf[jn], acc[jn][im], 0, 0, 0);
+  };
+  auto ldw = [&](f16x8 (&d)[3], const unsigned char* wb, int off) {
 #pragma unroll
-      for (int im = 0; im < 2; ++im) {
-        ah[c][im] = *reinterpret_cast<const f16x8*>(ab + ard[c][0] + im * 4096);
-        al[c][im] = *reinterpret_cast<const f16x8*>(ab + ard[c][1] + im * 4096);
-      }
-    }
+    for (int jn = 0; jn < 3; ++jn) d[jn] = *reinterpret_cast<const f16x8*>(wb + off + jn * 4096);
+  };
+  auto lda = [&](f16x8 (&d)[2], const unsigned char* ab, int off) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      // hi * hi
-      mm(wh[c][0], ah[c][0], acc[0][0]); mm(wh[c][0], ah[c][1], acc[0][1]); mm(wh[c][1], ah[c][0], acc[1][0]); mm(wh[c][1], ah[c][1], acc[1][1]);
-      mm(wh[c][2], ah[c][0], acc[2][0]); mm(wh[c][2], ah[c][1], acc[2][1]);
-      // hi * lo
-      mm(wh[c][0], al[c][0], acc[0][0]); mm(wh[c][0], al[c][1], acc[0][1]);
-      mm(wh[c][1], al[c][0], acc[1][0]); mm(wh[c][1], al[c][1], acc[1][1]); mm(wh[c][2], al[c][0], acc[2][0]); mm(wh[c][2], al[c][1], acc[2][1]);
-      // lo * hi
-      mm(wl[c][0], ah[c][0], acc[0][0]); mm(wl[c][0], ah[c][1], acc[0][1]); mm(wl[c][1], ah[c][0], acc[1][0]); mm(wl[c][1], ah[c][1], acc[1][1]);
-      mm(wl[c][2], ah[c][0], acc[2][0]); mm(wl[c][2], ah[c][1], acc[2][1]);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);  // all twenty fragment reads of the k-tile first, then the MFMAs
+    for (int im = 0; im < 2; ++im) d[im] = *reinterpret_cast<const f16x8*>(ab + off + im * 4096);
   };
 
   // ---- epilogues.  SWAP form: lane (l31, half) owns token row  m0 + wm*64 + 32 im + l31  and, per MFMA tile jn,
@@ -445,36 +446,82 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     return nv;
   };
 
-  // ---- the stream of the compute waves: one barrier per k-tile (the loader's), fragments + MFMAs, the epilogue after a
-  // tile's last k-tile.  Their only vector-memory work is the epilogue's loads and stores; nothing is ever waited for
-  // at the top of the loop.
+  // ---- the stream of the compute waves.  Their only vector-memory work is the epilogue's loads and stores.
   int cw = 0, ca = 0;  // slots of the position being computed
   const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
   unsigned long long* st = PROF ? p.stamps + ((size_t)EPI * 8 + wid) * 64 * 6 : nullptr;
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 6 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define FD_SB() __builtin_amdgcn_sched_barrier(0)
+  f16x8 ah0[2], al0[2], ah1[2], al1[2], wh0[3], wl0[3], wh1[3], wl1[3];
+  // first fragments (k16 step 0, hi planes) of the position in slots (cw, ca).  Their per-lane offset is re-derived from the
+  // lane id here: as a loop invariant it is the allocator's favourite spill victim (its only use follows a barrier), and a
+  // scratch reload is ~500 cycles during which no wave of the workgroup has a matrix instruction to issue.
+  auto first_fragments = [&]() {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int r00 = (ln & 31) * 128 + (((ln >> 5) ^ ((ln >> 1) & 7)) << 4);
+    lda(ah0, smem + abase + ca * A_STAGE, r00);
+    ldw(wh0, smem + wbase + cw * W_STAGE, r00);
+  };
+  auto groups_1_to_5 = [&]() {
+    const unsigned char* wb = smem + wbase + cw * W_STAGE;
+    const unsigned char* ab = smem + abase + ca * A_STAGE;
+    FD_SB();
+    lda(al0, ab, rd[0][1]);
+    mm6(wh0, ah0);
+    FD_SB();
+    ldw(wl0, wb, rd[0][1]);
+    mm6(wh0, al0);
+    FD_SB();
+    lda(ah1, ab, rd[1][0]);
+    ldw(wh1, wb, rd[1][0]);
+    mm6(wl0, ah0);
+    FD_SB();
+    lda(al1, ab, rd[1][1]);
+    mm6(wh1, ah1);
+    FD_SB();
+    ldw(wl1, wb, rd[1][1]);
+    mm6(wh1, al1);
+    FD_SB();
+    cw ^= 1;
+    ca = ca == NAS - 1 ? 0 : ca + 1;
+  };
+  barrier_keep_vm();  // position 0 landed (also publishes the EPI_LN parameter image)
+  first_fragments();
   for (int ti = 0; ti < cnt; ++ti) {
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {
       FD_STAMP(0);
+      groups_1_to_5();
       FD_STAMP(1);
-      barrier_keep_vm();  // (also publishes the EPI_LN parameter image before the first epilogue)
+      barrier_keep_vm();  // every fragment of this position is in registers: its slots are free; the next position landed
       FD_STAMP(2);
+      first_fragments();
+      FD_SB();  // reads first: they fly while group 6 runs
       FD_STAMP(3);
-      if constexpr (SWAP) {
-        compute(cw, ca, StreamYes{});
-      } else {
-        compute(cw, ca, StreamNo{});
-      }
+      mm6(wl1, ah1);
+      FD_SB();
       FD_STAMP(4);
-      cw ^= 1;
-      ca = ca == NAS - 1 ? 0 : ca + 1;
-      if (kt + 1 < nk) ++slot;
+      ++slot;
     }
+    // the tile's last k-tile: the epilogue sits between group 6 and the next tile's first fragments
+    FD_STAMP(0);
+    groups_1_to_5();
+    FD_STAMP(1);
+    const bool stream_end = ti + 1 == cnt;
+    if (!stream_end) barrier_keep_vm();
+    FD_STAMP(2);
+    FD_STAMP(3);
+    mm6(wl1, ah1);
+    FD_SB();
+    FD_STAMP(4);
     (void)epilogue(ti);
     FD_STAMP(5);
-    ++slot;
     zero_acc();
+    if (!stream_end) first_fragments();
+    ++slot;
   }
+#undef FD_SB
 #undef FD_STAMP
 }
 
@@ -490,7 +537,10 @@ static int n_cu_of_current_device() {
 }
 
 template <int EPI, bool SWAP>
-static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
+static void launch(const GemmImgArgs& p_in, int max_rows, hipStream_t s) {
+  static const int stagger = [] { const char* e = getenv("FDMI_STAGGER"); return e ? atoi(e) : 0; }();
+  GemmImgArgs p = p_in;
+  p.stagger = stagger;
   static bool attr_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
