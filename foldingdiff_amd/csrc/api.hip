@@ -184,17 +184,23 @@ void pack_split_weight(const float* W, int N, int K, std::vector<uint16_t>* out,
     }
 }
 
-// Row-image GEMM weights: the same 128-byte blocks, ordered [384-row tile][k-tile][row] so that the 48 KiB a workgroup
-// copies per k-tile are CONSECUTIVE cache lines (spread evenly over the L2 channels; with the row-major order the rows of
-// a k-tile are 4 K bytes apart and hit only some of the channels).  Rows padded to whole tiles with zeros.
+// Row-image GEMM weights, ordered [384-row tile][k-tile][48 KiB = the workgroup's LDS stage, byte for byte]: the loader copies a
+// k-tile with lane-linear LDS-DMA from CONSECUTIVE cache lines.  The stage is 48 pieces of 8 rows, each piece unit-major:
+// [piece j][position p][row % 8][16 B] with position p holding 16-byte unit p ^ (j & 1) of the row's block (the layout the
+// compute waves' fragment reads are bank-conflict free on; gemm_img.hip uses the same for the activation pieces).
+// Rows padded to whole tiles with zeros.
 void pack_weight_tiles(const float* W, int N, int K, std::vector<uint16_t>* out, float* scale) {
   std::vector<uint16_t> rm;
   pack_split_weight(W, N, K, &rm, scale, 384);
   const int npad = (N + 383) / 384 * 384, nk = K / 32;
   out->assign(rm.size(), 0);
   for (int n = 0; n < npad; ++n)
-    for (int kt = 0; kt < nk; ++kt)
-      memcpy(out->data() + ((((size_t)(n / 384) * nk + kt) * 384) + n % 384) * 64, rm.data() + ((size_t)n * nk + kt) * 64, 128);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int R = n % 384, j = R >> 3, r = R & 7;
+      uint16_t* stage = out->data() + ((size_t)(n / 384) * nk + kt) * 384 * 64;
+      const uint16_t* blk = rm.data() + ((size_t)n * nk + kt) * 64;
+      for (int u = 0; u < 8; ++u) memcpy(stage + (j * 1024 + (((u ^ (j & 1)) * 8 + r) << 4)) / 2, blk + u * 8, 16);
+    }
 }
 
 int upload_split(fd_model* m, SplitW* dst, const float* W, int N, int K, int row_pad = 128) {

@@ -19,7 +19,7 @@
 // A wave owns one 32-query row block; S^T (keys x queries) puts a query's scores in one lane pair, so softmax is
 // in-register and P is already the B operand of the PV MFMA; the relative_key term is dense 32x32 tiles
 // R = Q E^T over the band, skewed through a per-wave LDS scratch (see the comments inside).
-// ctx leaves as a row image [token row][head h block] for the attention-output GEMM.
+// ctx leaves as a grouped row image (img_common.h) with one 128-byte block per (token row, head) for the attention-output GEMM.
 #include <cstdlib>
 
 #include "fdmi_kernels.h"
@@ -409,8 +409,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       float o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = ok ? oacc[r] * onorm : 0.f;
-      unsigned char* dst = ok ? p.ctx + ((size_t)(row0 + l) * H + h) * 128 : p.trash;
-      store_block(dst, o, p.ctx_scale, half, true);
+      store_block_g(p.ctx, H, ok ? row0 + l : 0, h, o, p.ctx_scale, half, ok);  // grouped image: the rows of a unit are adjacent
     }
     stored_prev = item_ends;
     if (!done) {

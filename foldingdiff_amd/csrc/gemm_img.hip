@@ -128,10 +128,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // (g+1) & 1 and A slot (g+2) % 3.  The compute waves execute the same barriers and nothing else of this protocol.
   if (wid >= 8) {
     const int li = wid - 8;  // pieces j = li, li + NL, ...: all of one parity
-    const int swz_even = ((lane & 7) ^ (lane >> 4)) << 4, swz_odd = ((lane & 7) ^ (4 + (lane >> 4))) << 4;  // chunk j even / odd
-    const int vw_e = (lane >> 3) * 128 + swz_even, vw_o = (lane >> 3) * 128 + swz_odd;   // W: [tile][k-tile][row][128 B]
-    const int va_e = (lane >> 3) * rb + swz_even, va_o = (lane >> 3) * rb + swz_odd;     // A: row-major image
-    const int vw_l = (li & 1) ? vw_o : vw_e, va_l = (li & 1) ? va_o : va_e;  // even NL: a loader's pieces share one parity
+    const int vw = lane * 16;  // W: the HBM image of a (tile, k-tile) IS the LDS stage (api.hip: pack_weight_tiles)
+    // A: grouped image [row / 32][k-tile][unit][row % 32][16 B].  A piece = rows 8j..8j+7 x 8 units, read unit-major (eight
+    // neighbouring lanes fetch the eight rows of one unit = one 128-byte line) and therefore ALSO unit-major in LDS:
+    // [piece j][unit position p][row % 8][16 B], position p holding unit p ^ (j & 1) (bank-conflict-free fragment reads)
+    const int va_e = (lane >> 3) * 512 + (lane & 7) * 16, va_o = ((lane >> 3) ^ 1) * 512 + (lane & 7) * 16;
+    const int va_l = (li & 1) ? va_o : va_e;  // even NL: a loader's pieces share one parity
     int w_ti = 0, w_kt = 0, a_ti = 0, a_kt = 0, w_slot = 0, a_slot = 0, w_n0, a_m0;
     tile_mn(0, a_m0, w_n0);
     auto issue_w = [&]() {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
       for (int i = 0; i < 48 / NL; ++i) {
         const int j = li + i * NL;
-        dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? vw_o : vw_e) : vw_l, so + j * 1024);
+        dma16(rs, dst + j * 1024, vw, so + j * 1024);
       }
       w_slot ^= 1;
       if (w_ti * nk + w_kt + 1 < G) {  // past the end: re-issue the last position (lands in a free slot, never read)
@@ -156,13 +158,13 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     };
     auto issue_a = [&]() {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(p.A) + (size_t)a_m0 * rb, 0, BM * rb, 0x00020000);
+          const_cast<unsigned char*>(p.A) + (size_t)a_m0 * rb, 0, BM * rb, 0x00020000);  // the tile's four 32-row groups
       lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + a_slot * A_STAGE;
-      const int so = a_kt * 128;
+      const int so = a_kt * 4096;
 #pragma unroll
       for (int i = 0; i < 16 / NL; ++i) {
         const int j = li + i * NL;
-        dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + j * 8 * rb);
+        dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + (j >> 2) * 32 * rb + (j & 3) * 128);
       }
       a_slot = a_slot == NAS - 1 ? 0 : a_slot + 1;
       if (a_ti * nk + a_kt + 1 < G) {
@@ -204,12 +206,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // ---- fragment reads: rows wn*96 + 32 jn + l31 (W) / wm*64 + 32 im + l31 (A); every such row has
   // swizzle (l31 >> 1) & 7, so a lane needs four unit offsets per operand: [k16 step c][plane]
   // (one set of per-lane offsets serves both operands: the wave's row bases are wave-uniform and ride in the slot base)
-  const int sw = (l31 >> 1) & 7;
-  int rd[2][2];
+  int rd[2][2];  // both stages are unit-major pieces (see the loader): row l31 -> piece l31 / 8, unit u at position u ^ (piece & 1)
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) rd[c][pl] = l31 * 128 + (((2 * c + half + 4 * pl) ^ sw) << 4);  // ([0][0]: see first_fragments)
+    for (int pl = 0; pl < 2; ++pl)
+      rd[c][pl] = (l31 >> 3) * 1024 + ((((2 * c + half + 4 * pl) ^ ((l31 >> 3) & 1)) * 8 + (l31 & 7)) << 4);  // ([0][0]: see first_fragments)
   const int wbase = wn * 96 * 128, abase = OFF_A + wm * 64 * 128;
 
   f32x16 acc[3][2];  // [jn][im]
@@ -248,9 +250,13 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // the columns  n0 + wn*96 + 32 jn + 8q + 4 half + e  (register r = 4q + e): the quad layout of img_common.h.
   // Returns the wave's number of column blocks inside N (every such block issues exactly 8 store instructions:
   // pad rows are redirected to a scratch line instead of being predicated off, so the count is exact).
+  // (the lane indices are re-derived inside the epilogue from an opaque copy: as values that live across the whole tile
+  // loop they and everything computed from them get spilled, and a scratch reload behind stores waits for those stores)
   auto epilogue = [&](int ti) -> int {
-    int m0, n0;
+    int m0, n0, ln;
     tile_mn(ti, m0, n0);
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int l31 = ln & 31, half = ln >> 5;
     const float os = p.acc_scale;
     int nv = 0;
     if constexpr (EPI == EPI_IMG_GELU || EPI == EPI_IMG_BIAS) {
@@ -265,7 +271,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * q + 4 * half);
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
-          const int mrow = m0 + wm * 64 + im * 32 + l31;
           float o[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = gelu_erf(o[r]);
           }
-          store_block(p.out + ((size_t)mrow * nb + cb) * 128, o, p.out_scale, half, true);
+          store_group_block(p.out + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, o, p.out_scale, l31, half);
         }
       }
     } else if constexpr (EPI == EPI_IMG_QK) {
@@ -363,8 +368,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       // v = acc / (a_scale w_scale) + bias + residual (read back from its image)
 #pragma unroll
       for (int im = 0; im < 2; ++im) {
-        const int mrow = m0 + wm * 64 + im * 32 + l31;
-        const unsigned char* rrow = p.resid + (size_t)mrow * nb * 128;
 #pragma unroll
         for (int jn = 0; jn < 3; ++jn) {
           const int cb = wn * 3 + jn;
@@ -374,7 +377,9 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             continue;
           }
           float rv[16];
-          load_block(rrow + cb * 128, rv, p.resid_inv, half);
+          u32x4 raw[4];
+          load_group_block_raw(p.resid + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, raw, l31, half);
+          unpack_block(raw, rv, p.resid_inv);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float4 b4 = *reinterpret_cast<const float4*>(par + cb * 32 + 8 * q + 4 * half);
@@ -422,8 +427,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
       for (int im = 0; im < 2; ++im) {
         const float rstd = 1.0f / sqrtf(t2[im] * inv_n + p.eps);
-        const int mrow = m0 + wm * 64 + im * 32 + l31;
-        unsigned char* orow = p.out + (size_t)mrow * nb * 128;
 #pragma unroll
         for (int jn = 0; jn < 3; ++jn) {
           const int cb = wn * 3 + jn;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             o[4 * q + 2] = acc[jn][im][4 * q + 2] * rstd * g4.z + e4.z;
             o[4 * q + 3] = acc[jn][im][4 * q + 3] * rstd * g4.w + e4.w;
           }
-          store_block(orow + cb * 128, o, p.out_scale, half, true);
+          store_group_block(p.out + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, o, p.out_scale, l31, half);
         }
       }
     }
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   auto first_fragments = [&]() {
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    const int r00 = (ln & 31) * 128 + (((ln >> 5) ^ ((ln >> 1) & 7)) << 4);
+    const int r00 = ((ln & 31) >> 3) * 1024 + ((((ln >> 5) ^ ((ln >> 3) & 1)) * 8 + (ln & 7)) << 4);
     lda(ah0, smem + abase + ca * A_STAGE, r00);
     ldw(wh0, smem + wbase + cw * W_STAGE, r00);
   };

@@ -170,7 +170,6 @@ __global__ __launch_bounds__(256) void embed_img_kernel(EmbedImgArgs a) {
       }
     }
     row16_layernorm<NV>(v, gm, bt, ok, d, a.eps);
-    unsigned char* orow = a.h + (size_t)row * nb * 128;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       if (!ok[j]) continue;
@@ -180,9 +179,9 @@ __global__ __launch_bounds__(256) void embed_img_kernel(EmbedImgArgs a) {
                             : make_float4(0.f, 0.f, 0.f, 0.f);
       u32x2 hi, lo;
       split4(o, a.out_scale, hi, lo);
-      unsigned char* blk = orow + (grp >> 3) * 128 + 8 * (grp & 7);
+      unsigned char* blk = a.h + img_unit_offset(row, nb, grp >> 3, (grp & 7) >> 1) + 8 * (grp & 1);  // 4 columns = half a unit
       *reinterpret_cast<u32x2*>(blk) = hi;
-      *reinterpret_cast<u32x2*>(blk + 64) = lo;
+      *reinterpret_cast<u32x2*>(blk + 4 * 512) = lo;
     }
   }
 }
@@ -265,13 +264,13 @@ __global__ __launch_bounds__(256) void head_update_img_kernel(UpdateArgs a, Head
     const int row = tg * 16 + g;
     const int2 ri = row < rows ? ia.rowinfo[row] : make_int2(-1, -1);
     const bool real = ri.x >= 0 && ri.y < ia.nrow[ri.x >= 0 ? ri.x : 0];
-    const unsigned char* grow = ia.g + (size_t)(row < rows ? row : 0) * nb * 128;
+    const int grow = row < rows ? row : 0;
     float4 v[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int grp = ok[j] ? k + 16 * j : 0;
-      const unsigned char* blk = grow + (grp >> 3) * 128 + 8 * (grp & 7);
-      v[j] = join4(*reinterpret_cast<const u32x2*>(blk), *reinterpret_cast<const u32x2*>(blk + 64), ia.g_inv);
+      const unsigned char* blk = ia.g + img_unit_offset(grow, nb, grp >> 3, (grp & 7) >> 1) + 8 * (grp & 1);
+      v[j] = join4(*reinterpret_cast<const u32x2*>(blk), *reinterpret_cast<const u32x2*>(blk + 4 * 512), ia.g_inv);
     }
     if (a.do_ln) row16_layernorm<NV>(v, gm, bt, ok, d, a.ln_eps);
     float mine = 0.f;
@@ -317,9 +316,9 @@ __global__ void f32_to_img_kernel(const float* __restrict__ src, unsigned char* 
     const float4 v = r < src_rows ? *reinterpret_cast<const float4*>(src + r * K + 4 * grp) : make_float4(0.f, 0.f, 0.f, 0.f);
     u32x2 hi, lo;
     split4(v, s, hi, lo);
-    unsigned char* blk = dst + (r * (K >> 5) + (grp >> 3)) * 128 + 8 * (grp & 7);
+    unsigned char* blk = dst + img_unit_offset(r, K >> 5, grp >> 3, (grp & 7) >> 1) + 8 * (grp & 1);
     *reinterpret_cast<u32x2*>(blk) = hi;
-    *reinterpret_cast<u32x2*>(blk + 64) = lo;
+    *reinterpret_cast<u32x2*>(blk + 4 * 512) = lo;
   }
 }
 
@@ -329,9 +328,9 @@ __global__ void img_to_f32_kernel(const unsigned char* __restrict__ src, float* 
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / (K >> 2);
     const int grp = (int)(i - r * (K >> 2));
-    const unsigned char* blk = src + (r * (K >> 5) + (grp >> 3)) * 128 + 8 * (grp & 7);
+    const unsigned char* blk = src + img_unit_offset(r, K >> 5, grp >> 3, (grp & 7) >> 1) + 8 * (grp & 1);
     *reinterpret_cast<float4*>(dst + r * K + 4 * grp) =
-        join4(*reinterpret_cast<const u32x2*>(blk), *reinterpret_cast<const u32x2*>(blk + 64), inv_s);
+        join4(*reinterpret_cast<const u32x2*>(blk), *reinterpret_cast<const u32x2*>(blk + 4 * 512), inv_s);
   }
 }
 

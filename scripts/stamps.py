@@ -33,19 +33,18 @@ g = buf[: 5 * 8 * 64 * 6].reshape(5, 8, 64, 6).astype(np.int64)
 a = buf[5 * 8 * 64 * 6:].reshape(4, 64, 8).astype(np.int64)
 names = {0: "FFN-up/head GELU", 1: "attn-out / FFN-down LN (last launch = FFN-down K=768)", 2: "QK", 3: "V^T"}
 for epi in (2, 3, 1, 0):
-    print(f"== GEMM epilogue {epi}: {names[epi]}   [cycles of s_memtime, 100 MHz? see ratio]  wave 0 / wave 7")
-    for w in (0, 7):
+    print(f"== GEMM epilogue {epi}: {names[epi]}   [cycles of s_memtime]  wave 0 (group 0) / wave 4 (group 1)")
+    for w in (0, 4):
         s = g[epi, w]
         used = np.nonzero(s[:, 0])[0]
         if len(used) == 0:
             continue
-        print(f"  wave {w}: slots {len(used)}")
-        print("   slot   wait  barrier  issue  compute  epilogue   |  k-tile total")
-        for i in used[:40]:
+        print(f"  wave {w}: periods {len(used)}")
+        print("   period role   work  barrier  fetch  group6   |  period total   (role 1 = MFMA groups 1-5, 2 = epilogue chunk, 0 = idle)")
+        for i in used[:int(os.environ.get("NPER", 44))]:
             r = s[i]
             tot = (s[i + 1, 0] - r[0]) if i + 1 < 64 and s[i + 1, 0] else 0
-            epi_t = (r[5] - r[4]) if r[5] else 0
-            print(f"   {i:3d} {r[1]-r[0]:7d} {r[2]-r[1]:7d} {r[3]-r[2]:6d} {r[4]-r[3]:8d} {epi_t:9d}   | {tot:8d}")
+            print(f"   {i:3d}   {r[5]:2d} {r[1]-r[0]:7d} {r[2]-r[1]:7d} {r[3]-r[2]:6d} {r[4]-r[3]:7d}   | {tot:8d}")
 print("== attention: per position  [A]wait  barrier  S+band  [B]+issue  softmax+[C]wait  barrier  PV  | total")
 for w in (0, 3):
     s = a[w]
