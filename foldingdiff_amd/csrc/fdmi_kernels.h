@@ -129,7 +129,6 @@ struct GemmImgArgs {
   float eps;                   // LayerNorm eps
   float q_scale, k_scale, v_scale;
   unsigned long long* stamps;  // null, or [5 epilogues][8 waves][64 slots][6] cycle stamps of workgroup 0 (debug)
-  int stagger;                 // experiment (FDMI_STAGGER): workgroup class (blockIdx / 8) % 4 starts class x stagger cycles late
 };
 // max_rows bounds the grid (B * ceil8(L) of the workspace); the kernel reads the actual count from p.dims.
 void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s);

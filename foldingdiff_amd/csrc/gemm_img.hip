@@ -95,18 +95,17 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   const int cnt = first < thi ? (thi - first + stride - 1) / stride : 0;
   if (cnt == 0) return;
   const int G = cnt * nk;  // stream positions
-  if (p.stagger > 0) {  // experiment: de-phase the workgroups' store bursts
-    const long long wait = (long long)((blockIdx.x >> 3) & 3) * p.stagger, t0 = (long long)__builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
-
-  if constexpr (EPI == EPI_IMG_LN) {
+  {  // bias (all N <= 3 BN columns) or bias | gamma | beta (EPI_LN, N <= BN) -> LDS, published by the first barrier
     float* par = reinterpret_cast<float*>(smem + OFF_PAR);
-    for (int i = tid; i < BN; i += NTHR) {
-      const bool ok = i < p.N;
-      par[i] = ok ? p.bias[i] : 0.f;
-      par[BN + i] = ok ? p.gamma[i] : 0.f;
-      par[2 * BN + i] = ok ? p.beta[i] : 0.f;
+    if constexpr (EPI == EPI_IMG_LN) {
+      for (int i = tid; i < BN; i += NTHR) {
+        const bool ok = i < p.N;
+        par[i] = ok ? p.bias[i] : 0.f;
+        par[BN + i] = ok ? p.gamma[i] : 0.f;
+        par[2 * BN + i] = ok ? p.beta[i] : 0.f;
+      }
+    } else {
+      for (int i = tid; i < 3 * BN; i += NTHR) par[i] = i < p.N ? p.bias[i] : 0.f;
     }
   }
 
@@ -250,6 +249,21 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // the columns  n0 + wn*96 + 32 jn + 8q + 4 half + e  (register r = 4q + e): the quad layout of img_common.h.
   // Returns the wave's number of column blocks inside N (every such block issues exactly 8 store instructions:
   // pad rows are redirected to a scratch line instead of being predicated off, so the count is exact).
+  // (sequence, position) of the lane's token rows, fetched one k-tile before the epilogue needs them
+  int2 rinfo[4];  // EPI_QK: rows [im]; EPI_VT: token octets [2 im + u]
+  auto prefetch_rowinfo = [&](int ti) {
+    int m0, n0;
+    tile_mn(ti, m0, n0);
+    if constexpr (EPI == EPI_IMG_QK) {
+#pragma unroll
+      for (int im = 0; im < 2; ++im) rinfo[im] = p.rowinfo[m0 + wm * 64 + im * 32 + l31];
+    } else if constexpr (EPI == EPI_IMG_VT) {
+#pragma unroll
+      for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rinfo[2 * im + u] = p.rowinfo[m0 + wm * 64 + im * 32 + 16 * half + 8 * u];
+    }
+  };
   // (the lane indices are re-derived inside the epilogue from an opaque copy: as values that live across the whole tile
   // loop they and everything computed from them get spilled, and a scratch reload behind stores waits for those stores)
   auto epilogue = [&](int ti) -> int {
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     const int l31 = ln & 31, half = ln >> 5;
     const float os = p.acc_scale;
+    const float* par0 = reinterpret_cast<const float*>(smem + OFF_PAR);
     int nv = 0;
     if constexpr (EPI == EPI_IMG_GELU || EPI == EPI_IMG_BIAS) {
       const int nb = p.N >> 5;  // blocks per output row
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         ++nv;
         float4 b4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * q + 4 * half);
+        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       const int H = p.H;
       int2 ri[2];
 #pragma unroll
-      for (int im = 0; im < 2; ++im) ri[im] = p.rowinfo[m0 + wm * 64 + im * 32 + l31];
+      for (int im = 0; im < 2; ++im) ri[im] = rinfo[im];
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn;  // wave-uniform: block of the [q | k] column space
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         const int isk = cb >= H ? 1 : 0, h = cb - isk * H;
         float4 b4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(p.bias + cb * 32 + 8 * q + 4 * half);
+        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
         const float sc = isk ? p.k_scale : p.q_scale;
         const size_t pitch = (size_t)p.LTOT * 128;
         unsigned char* basep = isk ? p.kbuf : p.qbuf;
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         const int cb = (n0 >> 5) + wn * 3 + jn;
         if (cb >= H) continue;
         ++nv;
-        const float bz = p.bias[cb * 32 + l31];
+        const float bz = par0[cb * 32 + l31];
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           pack_block(o, p.v_scale, hh[0], hh[1], ll[0], ll[1]);
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int2 ri = p.rowinfo[m0 + wm * 64 + im * 32 + 16 * half + 8 * u];
+            const int2 ri = rinfo[2 * im + u];
             const bool ok = ri.x >= 0;
             const int lpos = ok ? ri.y : 0;
             const int kb = lpos >> 5, oc = (lpos & 31) >> 3;
@@ -509,6 +524,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     }
     // the tile's last k-tile: the epilogue sits between group 6 and the next tile's first fragments
     FD_STAMP(0);
+    prefetch_rowinfo(ti);
     groups_1_to_5();
     FD_STAMP(1);
     const bool stream_end = ti + 1 == cnt;
@@ -540,10 +556,7 @@ static int n_cu_of_current_device() {
 }
 
 template <int EPI, bool SWAP>
-static void launch(const GemmImgArgs& p_in, int max_rows, hipStream_t s) {
-  static const int stagger = [] { const char* e = getenv("FDMI_STAGGER"); return e ? atoi(e) : 0; }();
-  GemmImgArgs p = p_in;
-  p.stagger = stagger;
+static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
   static bool attr_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
