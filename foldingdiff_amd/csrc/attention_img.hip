@@ -3,8 +3,10 @@
 // triples on v_mfma_f32_32x32x16_f16 (fp32-class accuracy, see gemm_img.hip).
 //
 // Inputs are what the QK / V^T GEMM epilogues wrote, already split and already in the LDS layout:
-//     q   [b][h][LTOT rows][128 B]   hi d0-31 | lo d0-31
-//     k   [b][h][LTOT rows][128 B]   the same, 16-byte unit u of row r stored at u ^ ((r >> 1) & 7)  (conflict-free fetches)
+//     q, k  [b][h] grouped images (img_common.h): [position / 32][unit 0-7][position % 32][16 B], units 0-3 hi d0-31, 4-7 lo.
+//           k goes to LDS as unit-major pieces of 8 rows ([piece j][position p][row % 8][16 B], p holding unit p ^ (j & 1):
+//           conflict-free 16-byte operand fetches), copied with per-lane source offsets: eight neighbouring lanes read the
+//           eight rows of one unit = one 128-byte line
 //     vt  [b][h][32-key block][32 d][128 B]    V transposed: hi keys | lo keys as sixteen 8-byte units, unit u stored
 //                                               at u ^ ((d >> 1) & 15)  (conflict-free 8-byte operand fetches)
 // so filling LDS is a linear LDS-DMA copy: no VGPR round trip, no split arithmetic, no ds_write.
@@ -117,9 +119,18 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       dma16(rs, (lds_ptr_t)(dst_base) + piece * 1024, lane * 16, piece * 1024);
     }
   };
+  // K tile (LP keys = LP / 32 whole groups): piece j = keys 8j .. 8j+7; wave wq takes pieces wq, wq + 4, ... (all of wq's parity;
+  // KC = 4 T pieces: no clamping).  Lane -> (unit position lane / 8, key lane % 8).
+  const int kvoff = (((lane >> 3) ^ (wq & 1)) * 512) + (lane & 7) * 16;
   auto issue_k = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
-    copy(p.kbuf + (bh * p.LTOT + (size_t)s.kt * LP) * 128, G::K_BYTES, G::KC, G::KW, Ks);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(p.kbuf + (bh * p.LTOT + (size_t)s.kt * LP) * 128), 0, G::K_BYTES, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < G::KW; ++i) {
+      const int piece = wq + 4 * i;
+      dma16(rs, (lds_ptr_t)(Ks) + piece * 1024, kvoff, (piece >> 2) * 4096 + (piece & 3) * 128);
+    }
   };
   auto issue_v = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
@@ -128,8 +139,9 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   // Q operand of this lane: query l31 of the wave's row block, d = 16c + 8 half + j: units 2c + half (hi), 4 + 2c + half (lo)
   auto load_q = [&](const Pos& s, u32x4 (&q)[4]) {
     const size_t bh = (size_t)s.b * H + s.h;
-    const u32x4* row = reinterpret_cast<const u32x4*>(p.qbuf + (bh * p.LTOT + (size_t)s.qg * LP + 32 * (wq < T ? wq : 0) + l31) * 128);
-    q[0] = row[half]; q[1] = row[2 + half]; q[2] = row[4 + half]; q[3] = row[6 + half];
+    // the wave's 32 queries are one group of the grouped image: unit u of query l31 at (u * 32 + l31) * 16
+    const u32x4* grp0 = reinterpret_cast<const u32x4*>(p.qbuf + (bh * p.LTOT + (size_t)s.qg * LP + 32 * (wq < T ? wq : 0)) * 128);
+    q[0] = grp0[half * 32 + l31]; q[1] = grp0[(2 + half) * 32 + l31]; q[2] = grp0[(4 + half) * 32 + l31]; q[3] = grp0[(6 + half) * 32 + l31];
   };
 
   Pos cur, nxt;
@@ -204,12 +216,13 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-        const unsigned char* row = Ks + (size_t)(32 * t + l31) * 128;   // unit u of key row r at u ^ ((r >> 1) & 7)
-        const int ksz = (l31 >> 1) & 7;
+        // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
+        const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
+        const int ksz = (l31 >> 3) & 1;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const f16x8 kh = *reinterpret_cast<const f16x8*>(row + (((2 * c + half) ^ ksz) << 4));
-          const f16x8 kl = *reinterpret_cast<const f16x8*>(row + (((4 + 2 * c + half) ^ ksz) << 4));
+          const f16x8 kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
+          const f16x8 kl = *reinterpret_cast<const f16x8*>(pc + (((4 + 2 * c + half) ^ ksz) << 7));
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);

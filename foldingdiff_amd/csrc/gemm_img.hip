@@ -266,21 +266,19 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   // (the lane indices are re-derived inside the epilogue from an opaque copy: as values that live across the whole tile
   // loop they and everything computed from them get spilled, and a scratch reload behind stores waits for those stores)
-  auto epilogue = [&](int ti) -> int {
+  auto epilogue = [&](int ti) {
     int m0, n0, ln;
     tile_mn(ti, m0, n0);
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     const int l31 = ln & 31, half = ln >> 5;
     const float os = p.acc_scale;
     const float* par0 = reinterpret_cast<const float*>(smem + OFF_PAR);
-    int nv = 0;
     if constexpr (EPI == EPI_IMG_GELU || EPI == EPI_IMG_BIAS) {
       const int nb = p.N >> 5;  // blocks per output row
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn;  // wave-uniform
         if (cb >= nb) continue;
-        ++nv;
         float4 b4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
@@ -310,14 +308,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn;  // wave-uniform: block of the [q | k] column space
         if (cb >= 2 * H) continue;
-        ++nv;
         const int isk = cb >= H ? 1 : 0, h = cb - isk * H;
         float4 b4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
         const float sc = isk ? p.k_scale : p.q_scale;
-        const size_t pitch = (size_t)p.LTOT * 128;
-        unsigned char* basep = isk ? p.kbuf : p.qbuf;
+        unsigned char* basep = (isk ? p.kbuf : p.qbuf) + (size_t)h * p.LTOT * 128;  // + sequence * H * LTOT * 128 below
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -328,10 +324,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             o[4 * q + 2] = __builtin_fmaf(acc[jn][im][4 * q + 2], os, b4[q].z);
             o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3], os, b4[q].w);
           }
+          // q and k are grouped images per (sequence, head): [position / 32][unit][position % 32][16 B]; rows that are
+          // no token (alignment / tail rows) are not stored
           const bool ok = ri[im].x >= 0;
-          unsigned char* dst = ok ? basep + ((size_t)ri[im].x * H + h) * pitch + (size_t)ri[im].y * 128 : p.trash;
-          // k rows carry the LDS bank swizzle of the attention kernel (unit ^ ((position >> 1) & 7)); q rows are plain
-          store_block_swz(dst, o, sc, half, (isk && ok) ? ((ri[im].y >> 1) & 7) : 0);
+          store_block_g(basep + (size_t)(ok ? ri[im].x : 0) * H * p.LTOT * 128, 1, ok ? ri[im].y : 0, 0, o, sc, half, ok);
         }
       }
     } else if constexpr (EPI == EPI_IMG_VT) {
@@ -348,7 +344,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn;
         if (cb >= H) continue;
-        ++nv;
         const float bz = par0[cb * 32 + l31];
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
@@ -446,7 +441,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         for (int jn = 0; jn < 3; ++jn) {
           const int cb = wn * 3 + jn;
           if (cb >= nb) continue;
-          if (im == 0) ++nv;
           float o[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -461,7 +455,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         }
       }
     }
-    return nv;
   };
 
   // ---- the stream of the compute waves.  Their only vector-memory work is the epilogue's loads and stores.

@@ -334,7 +334,7 @@ __global__ void img_to_f32_kernel(const unsigned char* __restrict__ src, float* 
   }
 }
 
-// debug: q / k rows ([BH][LTOT][rowbytes], hi d0-31 | lo d0-31) or v^T blocks -> fp32 [BH][LTOT][32]
+// debug: q / k (grouped images per (sequence, head)) or v^T blocks -> fp32 [BH][LTOT][32]
 __global__ void qkv_unpack_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long BH, int LTOT,
                                   int LP, int rowbytes, int is_vt, float inv_s) {
   const long long n = BH * LTOT * 32;
@@ -349,11 +349,10 @@ __global__ void qkv_unpack_kernel(const unsigned char* __restrict__ src, float* 
       const unsigned char* r = src + (((bh * (LTOT >> 5) + kb) * 32) + dd) * (size_t)128;
       hp = reinterpret_cast<const _Float16*>(r + (((kl >> 2) ^ sz) << 3)) + (kl & 3);
       lp = reinterpret_cast<const _Float16*>(r + (((8 + (kl >> 2)) ^ sz) << 3)) + (kl & 3);
-    } else {  // is_vt == 2: k rows, 16-byte unit u stored at u ^ ((l >> 1) & 7)
-      const unsigned char* r = src + row * (size_t)rowbytes;
-      const int sz = is_vt == 2 ? (l >> 1) & 7 : 0;
-      hp = reinterpret_cast<const _Float16*>(r + (((dd >> 3) ^ sz) << 4)) + (dd & 7);
-      lp = reinterpret_cast<const _Float16*>(r + (((4 + (dd >> 3)) ^ sz) << 4)) + (dd & 7);
+    } else {  // q / k: grouped image per (sequence, head), [l / 32][unit][l % 32][16 B]
+      const unsigned char* g = src + bh * (size_t)LTOT * rowbytes;
+      hp = reinterpret_cast<const _Float16*>(g + img_unit_offset(l, 1, 0, dd >> 3)) + (dd & 7);
+      lp = reinterpret_cast<const _Float16*>(g + img_unit_offset(l, 1, 0, 4 + (dd >> 3))) + (dd & 7);
     }
     dst[i] = ((float)*hp + (float)*lp) * inv_s;
   }
