@@ -52,7 +52,7 @@ struct LayerDev {
   SplitW demb_s;  // distance table as an fp16 hi|lo row image (row-image attention)
   // row-image path: weight images padded to 384 rows, and the (static, power-of-two) scales of this layer's
   // activation images -- derived from norm bounds of the weights at fd_finalize, so nothing can overflow fp16
-  SplitW wqk_i, wv_i, wo_i, wi_i, wd_i;
+  SplitW wqk_i, wv_i, wqkv_i, wo_i, wi_i, wd_i;  // wqkv_i: q | k | v rows in one image (n_heads % 6 == 0: one launch)
   float *bqk = nullptr, *bv = nullptr;  // bias slices of bqkv
   float s_h = 1.f, s_q = 1.f, s_k = 1.f, s_v = 1.f, s_a = 1.f, s_g = 1.f;
   float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
@@ -128,6 +128,7 @@ struct fd_model {
   unsigned long long* stamps = nullptr;  // debug cycle stamps (FDMI_STAMPS=1): gemm [5][8][64][6] then attention [4][64][8]
   int debug_stop = 0;  // row-image path: stop a step after this many launches (debug dumps; 0 = off)
   int debug_layer = 0; // layer whose scales fd_debug_read uses
+  int split_qkv = 0; // row-image path: 1 = q | k and v^T as two launches even when one would do (A/B, tests)
   int varlen = 0;    // row-image path: only the first lens[b] positions of a sequence are token rows
   // workspaces (buffers + captured graph) are kept per (B, L): sample_length()-driven sampling and ragged chunks
   // alternate between a few shapes
@@ -329,7 +330,8 @@ int ensure_ws(fd_model* m, int B, int L) {
     double* by = m->prof_bytes;
     const bool img = m->img;
     fl[KC_EMBED] = 2 * Md * F * dd;            by[KC_EMBED] = 4 * (Md * F + Md * dd);
-    const int qn = img ? 2 : 3;  // the row-image path computes V (transposed) in its own launch
+    // the row-image path computes V (transposed) in its own launch unless n_heads % 6 == 0 (one q | k | v launch)
+    const int qn = (img && !(c.n_heads % 6 == 0 && !m->split_qkv)) ? 2 : 3;
     fl[KC_GEMM_QKV] = 2 * Md * qn * dd * dd;
     by[KC_GEMM_QKV] = 4 * (Md * dd + qn * dd * dd + Md * qn * dd);
     fl[KC_GEMM_V] = 2 * Md * dd * dd;          by[KC_GEMM_V] = 4 * (2 * Md * dd + dd * dd);
@@ -610,7 +612,15 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
   for (int li = 0; li < c.n_layers; ++li) {
     const LayerDev& lw = m->layers[li];
     const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
-    {
+    if (lw.wqkv_i.p && !m->split_qkv) {
+      // q | k | v in one launch: the three column tiles of a row panel run side by side on one XCD (h is read from HBM once)
+      GemmImgArgs g = base();
+      g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqkv_i.p); g.bias = lw.bqkv;
+      g.qbuf = w.qbuf; g.kbuf = w.kbuf; g.vbuf = w.vbuf; g.N = 3 * d; g.K = d;
+      g.acc_scale = 1.0f / (lw.s_h * lw.wqkv_i.scale); g.q_scale = lw.s_q; g.k_scale = lw.s_k; g.v_scale = lw.s_v;
+      PROF(KC_GEMM_QKV, launch_gemm_img(EPI_IMG_QKV, g, max_rows, s));
+      DBG_STOP();
+    } else {
       {
         GemmImgArgs g = base();
         g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqk_i.p); g.bias = lw.bqk;
@@ -1008,6 +1018,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     if (img) {
       if (int rc = upload_split(m, &lw.wqk_i, wqkv.data(), 2 * (int)d, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wv_i, wqkv.data() + 2 * d * d, (int)d, (int)d, 384)) return rc;
+      if (c.n_heads % 6 == 0)
+        if (int rc = upload_split(m, &lw.wqkv_i, wqkv.data(), 3 * (int)d, (int)d, 384)) return rc;
       lw.bqk = lw.bqkv;
       lw.bv = lw.bqkv + 2 * d;
       lw.s_h = scale_for(hb.linf);
@@ -1096,6 +1108,10 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   if (n == "fuse_ln") m->fuse_ln = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
   else if (n == "varlen") m->varlen = value ? 1 : 0;
+  else if (n == "split_qkv") {
+    m->split_qkv = value ? 1 : 0;
+    drop_workspaces(m);  // captured graphs hold the other launch sequence
+  }
   else if (n == "debug_stop") m->debug_stop = value;
   else if (n == "debug_layer") m->debug_layer = value;
   else return fail(FD_E_INVALID, "unknown option '%s'", name);

@@ -105,7 +105,11 @@ void launch_philox_fill(float* out, unsigned long long seed, int t, long long se
 // rowwise_img.hip.  Token rows: sequences start at multiples of 8 rows; `rowinfo[row]` = (sequence, position)
 // or (-1, -1) for padding rows; `dims` (device) = {rows, rows rounded up to 128}.  Every kernel is persistent /
 // grid-stride and reads the row counts from `dims`, so a captured graph serves any lengths of one (B, L).
-enum GemmImgEpilogue { EPI_IMG_GELU = 0, EPI_IMG_LN = 1, EPI_IMG_QK = 2, EPI_IMG_VT = 3, EPI_IMG_BIAS = 4 /* plain bias: test hook */ };
+enum GemmImgEpilogue {
+  EPI_IMG_GELU = 0, EPI_IMG_LN = 1, EPI_IMG_QK = 2, EPI_IMG_VT = 3, EPI_IMG_BIAS = 4 /* plain bias: test hook */,
+  EPI_IMG_QKV = 5  // q | k | v in ONE launch (N = 3 d_model; needs n_heads % 6 == 0 so that v starts on a 384-column tile):
+                   // column tiles below 2 d_model take the EPI_QK path, the others the EPI_VT path (stamps share EPI_QK's slot)
+};
 
 struct GemmImgArgs {
   const unsigned char* A;      // activation image [rows128][K/32][128 B]

@@ -27,12 +27,15 @@
 //    LayerNorm statistics are in-lane sums, and the output block is written with four 16-byte stores per
 //    32 x 32 tile after a half-wave register exchange (img_common.h) instead of sixteen 4-byte stores.
 #include <cstdlib>
+#include <type_traits>
 
 #include "fdmi_kernels.h"
 #include "img_common.h"
 
 namespace fdmi {
 namespace gi {
+
+template <int V> using IC = std::integral_constant<int, V>;
 
 struct StreamNo { static constexpr bool value = false; };
 struct StreamYes { static constexpr bool value = true; };
@@ -228,13 +231,13 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // The operands of a group are fetched while the previous group runs, and the barrier of the NEXT position sits before the
   // last group, so the first fragments of the next k-tile are on their way while this one finishes: the matrix pipe
   // never waits for a whole fragment set behind a barrier.
-  auto mm6 = [&](const f16x8 (&wf)[3], const f16x8 (&af)[2]) {
+  auto mm6 = [&](auto SW, const f16x8 (&wf)[3], const f16x8 (&af)[2]) {  // SW: swapped form (D^T = W A^T)
 #pragma unroll
     for (int jn = 0; jn < 3; ++jn)
 #pragma unroll
       for (int im = 0; im < 2; ++im)
-        acc[jn][im] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[jn], af[im], acc[jn][im], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], wf[jn], acc[jn][im], 0, 0, 0);
+        acc[jn][im] = decltype(SW)::value ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[jn], af[im], acc[jn][im], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], wf[jn], acc[jn][im], 0, 0, 0);
   };
   auto ldw = [&](f16x8 (&d)[3], const unsigned char* wb, int off) {
 #pragma unroll
@@ -251,13 +254,15 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // pad rows are redirected to a scratch line instead of being predicated off, so the count is exact).
   // (sequence, position) of the lane's token rows, fetched one k-tile before the epilogue needs them
   int2 rinfo[4];  // EPI_QK: rows [im]; EPI_VT: token octets [2 im + u]
-  auto prefetch_rowinfo = [&](int ti) {
+  auto prefetch_rowinfo = [&](auto SW, int ti) {
+    constexpr bool kQK = EPI == EPI_IMG_QK || (EPI == EPI_IMG_QKV && decltype(SW)::value);
+    constexpr bool kVT = EPI == EPI_IMG_VT || (EPI == EPI_IMG_QKV && !decltype(SW)::value);
     int m0, n0;
     tile_mn(ti, m0, n0);
-    if constexpr (EPI == EPI_IMG_QK) {
+    if constexpr (kQK) {
 #pragma unroll
       for (int im = 0; im < 2; ++im) rinfo[im] = p.rowinfo[m0 + wm * 64 + im * 32 + l31];
-    } else if constexpr (EPI == EPI_IMG_VT) {
+    } else if constexpr (kVT) {
 #pragma unroll
       for (int im = 0; im < 2; ++im)
 #pragma unroll
@@ -266,7 +271,9 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   // (the lane indices are re-derived inside the epilogue from an opaque copy: as values that live across the whole tile
   // loop they and everything computed from them get spilled, and a scratch reload behind stores waits for those stores)
-  auto epilogue = [&](int ti) {
+  auto epilogue = [&](auto SW, int ti) {
+    constexpr bool kQK = EPI == EPI_IMG_QK || (EPI == EPI_IMG_QKV && decltype(SW)::value);
+    constexpr bool kVT = EPI == EPI_IMG_VT || (EPI == EPI_IMG_QKV && !decltype(SW)::value);
     int m0, n0, ln;
     tile_mn(ti, m0, n0);
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           store_group_block(p.out + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, o, p.out_scale, l31, half);
         }
       }
-    } else if constexpr (EPI == EPI_IMG_QK) {
+    } else if constexpr (kQK) {
       const int H = p.H;
       int2 ri[2];
 #pragma unroll
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           store_block_g(basep + (size_t)(ok ? ri[im].x : 0) * H * p.LTOT * 128, 1, ok ? ri[im].y : 0, 0, o, sc, half, ok);
         }
       }
-    } else if constexpr (EPI == EPI_IMG_VT) {
+    } else if constexpr (kVT) {
       // normal MFMA form: lane = column (d = l31 of head cb), register r = 4q + e <-> token row 8q + 4 half + e of the
       // 32-row MFMA tile.  After the exchange the lower lane holds token octets 0, 1 and the upper lane 2, 3 of the
       // tile; sequences start at multiples of 8 rows, so an octet never straddles two sequences.
@@ -340,11 +347,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       // swizzle is odd -- so every store is an aligned 16-byte piece of a 128-byte line, as in the q / k epilogue.
       const int H = p.H, nkb = p.LTOT >> 5;
       const int sz = (l31 >> 1) & 15;
+      constexpr bool merged = EPI == EPI_IMG_QKV;  // v columns follow the 2 H blocks of q | k
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
-        const int cb = (n0 >> 5) + wn * 3 + jn;
+        const int cb = (n0 >> 5) + wn * 3 + jn - (merged ? 2 * H : 0);
         if (cb >= H) continue;
-        const float bz = par0[cb * 32 + l31];
+        const float bz = par0[(cb + (merged ? 2 * H : 0)) * 32 + l31];
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // ---- the stream of the compute waves.  Their only vector-memory work is the epilogue's loads and stores.
   int cw = 0, ca = 0;  // slots of the position being computed
   const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
-  unsigned long long* st = PROF ? p.stamps + ((size_t)EPI * 8 + wid) * 64 * 6 : nullptr;
+  unsigned long long* st = PROF ? p.stamps + ((size_t)(EPI == EPI_IMG_QKV ? (int)EPI_IMG_QK : EPI) * 8 + wid) * 64 * 6 : nullptr;
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 6 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define FD_SB() __builtin_amdgcn_sched_barrier(0)
@@ -475,63 +483,73 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     lda(ah0, smem + abase + ca * A_STAGE, r00);
     ldw(wh0, smem + wbase + cw * W_STAGE, r00);
   };
-  auto groups_1_to_5 = [&]() {
+  auto groups_1_to_5 = [&](auto SW) {
     const unsigned char* wb = smem + wbase + cw * W_STAGE;
     const unsigned char* ab = smem + abase + ca * A_STAGE;
     FD_SB();
     lda(al0, ab, rd[0][1]);
-    mm6(wh0, ah0);
+    mm6(SW, wh0, ah0);
     FD_SB();
     ldw(wl0, wb, rd[0][1]);
-    mm6(wh0, al0);
+    mm6(SW, wh0, al0);
     FD_SB();
     lda(ah1, ab, rd[1][0]);
     ldw(wh1, wb, rd[1][0]);
-    mm6(wl0, ah0);
+    mm6(SW, wl0, ah0);
     FD_SB();
     lda(al1, ab, rd[1][1]);
-    mm6(wh1, ah1);
+    mm6(SW, wh1, ah1);
     FD_SB();
     ldw(wl1, wb, rd[1][1]);
-    mm6(wh1, al1);
+    mm6(SW, wh1, al1);
     FD_SB();
     cw ^= 1;
     ca = ca == NAS - 1 ? 0 : ca + 1;
   };
-  barrier_keep_vm();  // position 0 landed (also publishes the EPI_LN parameter image)
-  first_fragments();
-  for (int ti = 0; ti < cnt; ++ti) {
+  auto run_tile = [&](auto SW, int ti) {
     for (int kt = 0; kt + 1 < nk; ++kt) {
       FD_STAMP(0);
-      groups_1_to_5();
+      groups_1_to_5(SW);
       FD_STAMP(1);
       barrier_keep_vm();  // every fragment of this position is in registers: its slots are free; the next position landed
       FD_STAMP(2);
       first_fragments();
       FD_SB();  // reads first: they fly while group 6 runs
       FD_STAMP(3);
-      mm6(wl1, ah1);
+      mm6(SW, wl1, ah1);
       FD_SB();
       FD_STAMP(4);
       ++slot;
     }
     // the tile's last k-tile: the epilogue sits between group 6 and the next tile's first fragments
     FD_STAMP(0);
-    prefetch_rowinfo(ti);
-    groups_1_to_5();
+    prefetch_rowinfo(SW, ti);
+    groups_1_to_5(SW);
     FD_STAMP(1);
     const bool stream_end = ti + 1 == cnt;
     if (!stream_end) barrier_keep_vm();
     FD_STAMP(2);
     FD_STAMP(3);
-    mm6(wl1, ah1);
+    mm6(SW, wl1, ah1);
     FD_SB();
     FD_STAMP(4);
-    (void)epilogue(ti);
+    epilogue(SW, ti);
     FD_STAMP(5);
     zero_acc();
     if (!stream_end) first_fragments();
     ++slot;
+  };
+  barrier_keep_vm();  // position 0 landed (also publishes the parameter image)
+  first_fragments();
+  for (int ti = 0; ti < cnt; ++ti) {
+    if constexpr (EPI == EPI_IMG_QKV) {  // the v tiles run the normal MFMA form (lane = feature), the q | k tiles the swapped one
+      int m0, n0;
+      tile_mn(ti, m0, n0);
+      if (n0 >= 2 * p.H * 32) run_tile(IC<0>{}, ti);
+      else run_tile(IC<1>{}, ti);
+    } else {
+      run_tile(IC<SWAP ? 1 : 0>{}, ti);
+    }
   }
 #undef FD_SB
 #undef FD_STAMP
@@ -576,6 +594,7 @@ void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream
     case EPI_IMG_LN: gi::launch<EPI_IMG_LN, true>(p, max_rows, s); break;
     case EPI_IMG_QK: gi::launch<EPI_IMG_QK, true>(p, max_rows, s); break;
     case EPI_IMG_BIAS: gi::launch<EPI_IMG_BIAS, true>(p, max_rows, s); break;
+    case EPI_IMG_QKV: gi::launch<EPI_IMG_QKV, true>(p, max_rows, s); break;
     default: gi::launch<EPI_IMG_VT, false>(p, max_rows, s); break;
   }
 }

@@ -102,15 +102,22 @@ def main(name):
         print(f"  {tag:8s} max|d| = {worst:.3e}   (max|want| = {scale:.3e})  at {where}")
         return worst
 
-    print(f"== {name}: d={d} H={H} ff={ff} L={L} lens={lens}")
+    split = int(os.environ.get("SPLIT_QKV", "0"))
+    pm.set_option("split_qkv", split)
+    merged = H % 6 == 0 and not split   # q | k | v in one launch: one stage less
+    print(f"== {name}: d={d} H={H} ff={ff} L={L} lens={lens}  ({'one q|k|v launch' if merged else 'q|k and v launches'})")
     run(1); report("h", rows_img("h", d), cap["h"], valid_only=False)
-    run(2); report("q", qkv("q"), cap["q"], False); report("k", qkv("k"), cap["k"], False)
-    run(3); report("v", qkv("v"), cap["v"], False)
-    run(4); report("ctx", rows_img("ctx", d), cap["ctx"], False)
-    run(5); report("a", rows_img("a", d), cap["a"], False)
-    run(6); report("g", rows_img("g", ff), cap["g"], False)
-    run(7); report("h_out", rows_img("h_out", d), cap["h_out"], False)
-    run(8); report("g_head", rows_img("g_head", d), cap["g_head"], False)
+    n = 2
+    run(n); report("q", qkv("q"), cap["q"], False); report("k", qkv("k"), cap["k"], False)
+    if not merged:
+        n += 1
+        run(n)
+    report("v", qkv("v"), cap["v"], False)
+    run(n + 1); report("ctx", rows_img("ctx", d), cap["ctx"], False)
+    run(n + 2); report("a", rows_img("a", d), cap["a"], False)
+    run(n + 3); report("g", rows_img("g", ff), cap["g"], False)
+    run(n + 4); report("h_out", rows_img("h_out", d), cap["h_out"], False)
+    run(n + 5); report("g_head", rows_img("g_head", d), cap["g_head"], False)
     got = run(0)
     report("eps", got, want_eps, False)
 

@@ -18,6 +18,8 @@ torch.manual_seed(0)
 model = modelling.BertForDiffusionBase(modelling.BertConfig(**RELEASED), [True] * 6).to("cuda:0")
 betas = beta_schedules.cosine_beta_schedule(1000)
 h = model.prepare(betas)
+if os.environ.get("SPLIT_QKV"):
+    model.set_option("split_qkv", int(os.environ["SPLIT_QKV"]))
 lib = _binding.load()
 x = torch.randn(B, L, 6, device="cuda:0")
 lens = torch.full((B,), L, dtype=torch.int32, device="cuda:0")
