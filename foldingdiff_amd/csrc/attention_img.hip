@@ -30,6 +30,8 @@
 namespace fdmi {
 namespace ai {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr float PS = 1024.0f;  // probabilities are <= 1
 constexpr float kLog2e = 1.44269504088896341f;
 constexpr float kInvSqrtD = 0.17677669529663687f;  // 1 / sqrt(32)
@@ -144,6 +146,15 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     q[0] = grp0[half * 32 + l31]; q[1] = grp0[(2 + half) * 32 + l31]; q[2] = grp0[(4 + half) * 32 + l31]; q[3] = grp0[(6 + half) * 32 + l31];
   };
 
+  // band weights of the relative_key skew (see the S phase): r_scale where register r of this lane belongs to the lower /
+  // upper S^T tile of a band tile's pair, else 0
+  float bw_lo[16], bw_hi[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+    bw_lo[r] = (REL && l31 <= kl) ? p.r_scale : 0.f;
+    bw_hi[r] = (REL && l31 > kl) ? p.r_scale : 0.f;
+  }
   Pos cur, nxt;
   load_item(cur, NG * blockIdx.x + grp);
   u32x4 qn[4];
@@ -210,12 +221,11 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     }
 
     f32x16 sacc[T];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
       // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale)
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
         // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
         const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
         const int ksz = (l31 >> 3) & 1;
@@ -223,7 +233,8 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
         for (int c = 0; c < 2; ++c) {
           const f16x8 kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
           const f16x8 kl = *reinterpret_cast<const f16x8*>(pc + (((4 + 2 * c + half) ^ ksz) << 7));
-          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc[t], 0, 0, 0);
+          // (the first product starts from the inline constant 0: no accumulator zeroing pass)
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
         }
@@ -234,7 +245,6 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
         // (q = T-1-t, q+1): j < 32 -> tile q, else tile q+1 column j-32.  Band row of R tile q, column l31:
         //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + 32 q + l31, clamped: rows outside the table are only
         // ever paired with padding keys / queries (L <= maxpos).
-        const float r_ratio = p.r_scale;  // k_scale / table scale: band sums -> the raw scale of the scores
 #pragma unroll
         for (int qq = 0; qq <= T; ++qq) {
           int m = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * qq;
@@ -252,12 +262,10 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
             e0 = erow[half]; e1 = erow[2 + half]; e2 = erow[4 + half]; e3 = erow[6 + half];
           }
           f32x16 racc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
           {
             const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
             const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], eh0, racc, 0, 0, 0);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], eh0, zero16, 0, 0, 0);
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], el0, racc, 0, 0, 0);
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[0], eh0, racc, 0, 0, 0);
             racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], eh1, racc, 0, 0, 0);
@@ -297,19 +305,15 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
             const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
             gth[r] = Rrow[(l31 - kl + 31) & 31];
           }
+          // band weights bw_lo / bw_hi (r_ratio where the element belongs to the lower / upper tile of the pair, else 0): one
+          // fma per element and tile instead of a select + fma (band values are finite MFMA sums, so 0 * value = 0)
           if (qq < T) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-              sacc[T - 1 - qq][r] = __builtin_fmaf((l31 <= kl) ? gth[r] : 0.f, r_ratio, sacc[T - 1 - qq][r]);
-            }
+            for (int r = 0; r < 16; ++r) sacc[T - 1 - qq][r] = __builtin_fmaf(gth[r], bw_lo[r], sacc[T - 1 - qq][r]);
           }
           if (qq > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-              sacc[T - qq][r] = __builtin_fmaf((l31 > kl) ? gth[r] : 0.f, r_ratio, sacc[T - qq][r]);
-            }
+            for (int r = 0; r < 16; ++r) sacc[T - qq][r] = __builtin_fmaf(gth[r], bw_hi[r], sacc[T - qq][r]);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next band tile overwrites this scratch
           __builtin_amdgcn_wave_barrier();
@@ -383,14 +387,17 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          f16x8 ph, pl;
+          // p = hi + lo, pairwise: v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32
+          u32x4 phu, plu;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xs = sacc[t][8 * c + j];
-            const _Float16 hv = (_Float16)xs;
-            ph[j] = hv;
-            pl[j] = (_Float16)(xs - (float)hv);
+          for (int j = 0; j < 4; ++j) {
+            const f32x2 xv = {sacc[t][8 * c + 2 * j], sacc[t][8 * c + 2 * j + 1]};
+            const f16x2 hv = __builtin_convertvector(xv, f16x2);
+            const f32x2 rest = xv - __builtin_convertvector(hv, f32x2);
+            phu[j] = __builtin_bit_cast(unsigned, hv);
+            plu[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(rest, f16x2));
           }
+          const f16x8 ph = __builtin_bit_cast(f16x8, phu), pl = __builtin_bit_cast(f16x8, plu);
           // V operand of key block t: keys 16c + 4 half + {0..3} = unit 4c + half, and + 8 = unit 4c + half + 2; lo plane + 8
           const unsigned char* blk = vrow + t * 4096;
           const int ua = 4 * c + half;

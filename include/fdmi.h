@@ -117,6 +117,8 @@ void fd_destroy(fd_model* m);
  *                (the reference computes them and sampling.sample cuts them away, sampling.py:56-58, :201-203);
  *                positions < lens[b] are bit-identical either way.  Padded positions of `out` then keep x_init.
  *                0 (default): every position evolves as in the reference's p_sample_loop.
+ *   "split_qkv"  FD_PREC_F16X3: 1 = project q | k and v^T in two launches even when n_heads % 6 == 0 would allow one
+ *                (A/B measurements, tests); 0 (default).
  *   "debug_stop" n > 0: a step returns after its first n launches (FD_PREC_F16X3; stage-by-stage comparison with
  *                fd_debug_read, scripts/debug_img.py); "debug_layer": which encoder layer fd_debug_read sees. */
 int fd_set_option(fd_model* m, const char* name, int value);
