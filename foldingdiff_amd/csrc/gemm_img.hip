@@ -1,31 +1,38 @@
 // Token GEMMs of the encoder on row images (img_common.h): fp32-class accuracy on the fp16 matrix cores.
 //
-//   C[M,N] = A[M,K] * W[N,K]^T + bias[N]   then one of four epilogues
-//     EPI_QK    q | k of HF BertSelfAttention (transformers 4.11.3, called from foldingdiff/modelling.py:473-480)
-//               scattered per (sequence, head) as 128-byte rows (k: units swizzled) that the attention kernel copies into LDS
+//   C[M,N] = A[M,K] * W[N,K]^T + bias[N]   then one of these epilogues
+//     EPI_QK    q | k of HF BertSelfAttention (transformers 4.11.3, called from foldingdiff/modelling.py:473-480), stored as
+//               grouped images per (sequence, head) that the attention kernel reads with contiguous accesses
 //     EPI_VT    v, written transposed per (sequence, head, 32-key block): [d][hi keys | lo keys], swizzled
+//     EPI_QKV   both in ONE launch (n_heads % 6 == 0: v starts on a 384-column tile)
 //     EPI_GELU  BertIntermediate.dense / AnglesPredictor.dense1 + exact-erf GELU (modelling.py:195-196, :203-205)
 //     EPI_LN    BertSelfOutput / BertOutput: LayerNorm(dense(x) + residual)
 //
 // Arithmetic: a product a*w is  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi  on three v_mfma_f32_32x32x16_f16 into one
 // fp32 accumulator (fp16 x fp16 products are exact in fp32; the dropped lo*lo term is 2^-22 relative).
 //
-// What is different from a register-staged split GEMM:
-//  * the weight image is stored [384-row tile][k-tile][row][128 B]: a k-tile's 48 KiB are consecutive cache lines
-//  * BOTH operands already live in HBM as hi|lo row images (activations are written that way by every
-//    producer epilogue), so a k-tile (32 k = one 128-byte block per row) is staged with LDS-DMA
-//    (buffer_load_dwordx4 ... lds): no VGPR round trip, no split arithmetic, no ds_write in the k-loop.
-//    The LDS image is lane-linear; the bank swizzle (16-byte unit ^= (row >> 1) & 7) is applied to the
-//    per-lane SOURCE address and to the fragment reads.
-//  * 128 (M) x 384 (N) block, 8 waves as 2 (M) x 4 (N), wave tile 64 x 96 = 2 x 3 MFMA tiles (96 accumulators),
-//    18 MFMAs per 10 fragment fetches.  W ring: 2 stages (always L2 hits), A ring: 3 stages (the HBM stream,
-//    issued two k-tiles ahead), ONE workgroup barrier per k-tile, counted s_waitcnt vmcnt (never 0 in the loop).
-//    A ninth wave is the loader: it issues every LDS-DMA piece, the eight compute waves only read fragments and issue MFMAs.
-//  * persistent: one workgroup per CU walks an XCD-aware tile list; the (tile, k-tile) pairs form one
-//    continuous stream, so the next tile's operands are in flight during the epilogue.
-//  * "swapped" MFMA form (D^T = W A^T; all epilogues but EPI_VT): a lane owns ONE token row and 16 columns, so
-//    LayerNorm statistics are in-lane sums, and the output block is written with four 16-byte stores per
-//    32 x 32 tile after a half-wave register exchange (img_common.h) instead of sixteen 4-byte stores.
+// Structure (one persistent workgroup per CU: 8 compute waves + NL loader waves):
+//  * BOTH operands live in HBM as hi|lo images, so a k-tile (32 k = one 128-byte block per row) is staged with LDS-DMA
+//    (buffer_load_dwordx4 ... lds): no VGPR round trip, no split arithmetic, no ds_write in the k-loop.  A stage is a
+//    sequence of 1 KiB pieces of 8 rows, each piece UNIT-major ([position p][row % 8][16 B], p holding unit p ^ (piece & 1)):
+//    eight neighbouring lanes copy the eight rows of one unit, which are one 128-byte line of the grouped activation
+//    image, and the fragment reads (ds_read_b128) are bank-conflict free.  The weight image in HBM is the stage byte for
+//    byte ([384-row tile][k-tile][48 KiB], api.hip: pack_weight_tiles).
+//  * loader waves issue every piece, paced by counted s_waitcnt vmcnt and a raw s_barrier that leaves the vector-memory
+//    queue alone (one wave sustains ~22 B/clk out of L2, two ~40: scripts/probes/dma_probe.hip).  W ring 2 stages (L2
+//    hits), A ring 3 stages (the HBM stream, two k-tiles ahead), ONE workgroup barrier per k-tile.
+//  * 128 (M) x 384 (N) tile, 8 waves as 2 (M) x 4 (N), wave tile 64 x 96 = 2 x 3 MFMA tiles (96 accumulators).  A k-tile is
+//    six groups of six MFMAs; the operands of a group are fetched while the previous group runs, and the barrier of the
+//    NEXT k-tile sits before the last group, so the first fragments of the next k-tile fly while this one finishes.
+//  * persistent: an XCD-aware tile list, the (tile, k-tile) pairs form one continuous stream; the column tiles of one
+//    A panel run side by side on one XCD (one HBM read).
+//  * "swapped" MFMA form (D^T = W A^T; everything but the v tiles): a lane owns ONE token row and 16 columns, so LayerNorm
+//    statistics are in-lane sums, and a block is written with four 16-byte stores per lane after a half-wave register
+//    exchange (img_common.h); the grouped image layout makes each of those stores 512 contiguous bytes per half-wave.
+//  What bounds it (profiles/r02_gemm_ablation.log, r02_probes.log): MFMA and VALU instructions of different waves do NOT
+//  overlap on a SIMD (co-issue probe), so epilogue arithmetic adds to the matrix time; and when all 256 CUs store at once
+//  the chip takes ~5.4 TB/s = 10 B/clk per CU (one CU alone: 72 B/clk), so every tile's 196 KiB burst costs ~9 us during
+//  which the CU's loads queue behind its stores.
 #include <cstdlib>
 #include <type_traits>
 
@@ -37,8 +44,6 @@ namespace gi {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
-struct StreamNo { static constexpr bool value = false; };
-struct StreamYes { static constexpr bool value = true; };
 
 #ifndef FDMI_NL
 #define FDMI_NL 2
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   const int cnt = first < thi ? (thi - first + stride - 1) / stride : 0;
   if (cnt == 0) return;
   const int G = cnt * nk;  // stream positions
+
   {  // bias (all N <= 3 BN columns) or bias | gamma | beta (EPI_LN, N <= BN) -> LDS, published by the first barrier
     float* par = reinterpret_cast<float*>(smem + OFF_PAR);
     if constexpr (EPI == EPI_IMG_LN) {
