@@ -326,7 +326,6 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
         const float sc = isk ? p.k_scale : p.q_scale;
-        unsigned char* basep = (isk ? p.kbuf : p.qbuf) + (size_t)h * p.LTOT * 128;  // + sequence * H * LTOT * 128 below
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -340,7 +339,8 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           // q and k are grouped images per (sequence, head): [position / 32][unit][position % 32][16 B]; rows that are
           // no token (alignment / tail rows) are not stored
           const bool ok = ri[im].x >= 0;
-          store_block_g(basep + (size_t)(ok ? ri[im].x : 0) * H * p.LTOT * 128, 1, ok ? ri[im].y : 0, 0, o, sc, half, ok);
+          // (sequence, head) base folded into the row index of a one-block-per-row image: row = (b H + h) LTOT + position
+          store_block_g(isk ? p.kbuf : p.qbuf, 1, ok ? ((long long)ri[im].x * H + h) * p.LTOT + ri[im].y : 0, 0, o, sc, half, ok);
         }
       }
     } else if constexpr (kVT) {
@@ -372,12 +372,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             const bool ok = ri.x >= 0;
             const int lpos = ok ? ri.y : 0;
             const int kb = lpos >> 5, oc = (lpos & 31) >> 3;
-            unsigned char* row = ok ? p.vbuf + ((((size_t)ri.x * H + cb) * nkb + kb) * 32 + l31) * 128 : p.trash;
             u32x4 vh = hh[u], vl = ll[u];
             if (sz & 1) {
               vh = u32x4{vh[2], vh[3], vh[0], vh[1]};
               vl = u32x4{vl[2], vl[3], vl[0], vl[1]};
             }
+            unsigned char* row = ok ? p.vbuf + ((((size_t)ri.x * H + cb) * nkb + kb) * 32 + l31) * 128 : p.trash;
             *reinterpret_cast<u32x4*>(row + ((oc ^ (sz >> 1)) << 4)) = vh;
             *reinterpret_cast<u32x4*>(row + (((4 + oc) ^ (sz >> 1)) << 4)) = vl;
           }
