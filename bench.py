@@ -47,8 +47,9 @@ PRECISION_INFO = {
     "f32": dict(peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
                 kernel="gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384; v_mfma_f32_32x32x2_f32)"),
     "f16x3": dict(peak=PEAK_F16_MFMA_TFLOPS, dtype="f32 (fp16 hi/lo split operands, 3x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
-                  kernel="gi::gemm_img_kernel<EPI_IMG_QK> = 128x384-tile LDS-DMA-staged split GEMM on fp16 hi|lo row images (q|k projection, "
-                         "M=B*L, N=768, K=384; algorithmic FLOPs counted once, the 3 MFMAs per product are overhead against the dense fp16 peak)"),
+                  kernel="gi::gemm_img_kernel<EPI_IMG_QKV> = 128x384-tile LDS-DMA-staged split GEMM on fp16 hi|lo grouped row images (q|k|v "
+                         "projection in one launch, M=B*L, N=1152, K=384; algorithmic FLOPs counted once, the 3 MFMAs per product are overhead "
+                         "against the dense fp16 peak)"),
 }
 
 
