@@ -30,7 +30,6 @@
 namespace fdmi {
 namespace ai {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float PS = 1024.0f;  // probabilities are <= 1
 constexpr float kLog2e = 1.44269504088896341f;
@@ -387,15 +386,14 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          // p = hi + lo, pairwise: v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32
+          // p = hi + lo, pairwise (img_common.h: split_pair)
           u32x4 phu, plu;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const f32x2 xv = {sacc[t][8 * c + 2 * j], sacc[t][8 * c + 2 * j + 1]};
-            const f16x2 hv = __builtin_convertvector(xv, f16x2);
-            const f32x2 rest = xv - __builtin_convertvector(hv, f32x2);
-            phu[j] = __builtin_bit_cast(unsigned, hv);
-            plu[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(rest, f16x2));
+            unsigned hv, lv;
+            split_pair(sacc[t][8 * c + 2 * j], sacc[t][8 * c + 2 * j + 1], hv, lv);
+            phu[j] = hv;
+            plu[j] = lv;
           }
           const f16x8 ph = __builtin_bit_cast(f16x8, phu), pl = __builtin_bit_cast(f16x8, plu);
           // V operand of key block t: keys 16c + 4 half + {0..3} = unit 4c + half, and + 8 = unit 4c + half + 2; lo plane + 8
