@@ -124,15 +124,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     n0 = (tile - (tile / tiles_n) * tiles_n) * BN;
   };
 
-  // ================================================================ the loader wave
-  // Wave 8 issues every LDS-DMA piece of the workgroup: per k-tile 48 W pieces + 16 A pieces of 1 KiB (8 rows x 128 B;
-  // lane -> row 8 j + lane / 8, LDS unit lane % 8, fetched from source unit (lane % 8) ^ swizzle(row)).  A wave that
-  // issues a piece stalls until the CU's vector-memory path accepts it (the path moves ~20 B/clk/CU out of L2 here and is
-  // busy most of a k-tile); with the pieces spread over the compute waves those stalls sat between their MFMAs (k-loop
-  // 107 us, against 72 us without any DMA and 80 us for the DMA stream alone: profiles/r02_gemm_ablation.log).  Now the
-  // compute waves only read fragments and issue MFMAs, and the copy stream runs beside them at its own pace.
-  //   prologue A(0) W(0) A(1);  iteration g:  [vmcnt(16): W(g), A(g) landed] [barrier g] W(g+1) A(g+2)
-  // The barrier publishes k-tile g to the compute waves and tells the loader that compute(g-1) is over, which frees W slot
+  // ================================================================ the loader waves
+  // They issue every LDS-DMA piece of the workgroup: per k-tile 48 W pieces + 16 A pieces of 1 KiB (8 rows x 8 units,
+  // unit-major).  With the pieces spread over the compute waves the issue stalls sat between their MFMAs; here the compute
+  // waves only read fragments and issue MFMAs, and the copy stream runs beside them at its own pace.
+  //   prologue A(0) W(0) A(1);  iteration g:  [vmcnt: W(g), A(g) landed] [barrier g] W(g+1) A(g+2)
+  // The barrier publishes k-tile g to the compute waves and tells the loaders that compute(g-1) is over, which frees W slot
   // (g+1) & 1 and A slot (g+2) % 3.  The compute waves execute the same barriers and nothing else of this protocol.
   if (wid >= 8) {
     const int li = wid - 8;  // pieces j = li, li + NL, ...: all of one parity
