@@ -12,7 +12,7 @@
 // Activation images are stored GROUPED:  [row / 32][K / 32][unit 0..7][row % 32][16 B]  (img_unit_offset).  The producers'
 // lanes own token ROWS (swapped MFMA form, one 16-byte unit per lane and store), so with the rows of a unit adjacent a
 // store instruction writes 512 contiguous bytes per half-wave; with row-major blocks the same instruction scattered
-// sixteen-byte pieces over 64 lines (measured: 0.9 ms of an 8.2 ms timestep, profiles/r02_gemm_ablation.log).  A consumer's
+// sixteen-byte pieces over 64 lines (same-box: 8.74 -> 8.25 ms per timestep, profiles/r02_gemm_ablation.log).  A consumer's
 // LDS-DMA piece (8 rows x 8 units) still reads whole 128-byte lines: eight rows of one unit are contiguous.
 // Weight images and the attention operands (q, k, v^T, distance table) keep their own layouts.
 #pragma once
@@ -26,8 +26,7 @@ namespace fdmi {
 #endif
 
 #ifndef FDMI_EPI_DBG
-#define FDMI_EPI_DBG 0  // ablation builds (wrong results): 1 = the GEMM epilogues compute but do not store, 2 = no epilogue at all,
-                        // 3 = the same bytes to the same lines, but 8 consecutive lanes write one whole 128-byte line
+#define FDMI_EPI_DBG 0  // ablation build (wrong results): 1 = the epilogues compute but do not store (profiles/r02_gemm_ablation.log)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -123,52 +122,8 @@ __device__ __forceinline__ void pack_block(const float (&v)[16], float s, u32x4&
   l1 = u32x4{Lo[4], Lo[5], Lo[6], Lo[7]};
 }
 
-// ablation 3: lane L writes unit (L & 7) of the line owned by lane (L >> 3) + 8 k of its half-wave ... (garbage data, same footprint)
-__device__ __forceinline__ void store_lines_coalesced(unsigned char* blk, const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& d) {
-  const int L = __lane_id();
-  const u32x4 v[4] = {a, b, c, d};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int src = (L & 32) + ((L & 31) >> 3) + 8 * k;  // a lane of the same half-wave (rows differ per half only by plane in the real code)
-    const unsigned lo = __shfl((unsigned)(uintptr_t)blk, src), hi = __shfl((unsigned)((uintptr_t)blk >> 32), src);
-    unsigned char* line = reinterpret_cast<unsigned char*>(((uintptr_t)hi << 32) | lo);
-    reinterpret_cast<u32x4*>(line)[L & 7] = v[k];
-  }
-}
-
-// Store v (quad layout) as one 128-byte block at `blk` (this lane pair's row).  Every lane takes part in
+// Store v (quad layout) as block cb of token row `row` (this lane pair's row) of a GROUPED image.  Every lane takes part in
 // the exchange; only lanes with `pred` store.
-__device__ __forceinline__ void store_block(unsigned char* blk, const float (&v)[16], float s, int half, bool pred) {
-  u32x4 h0, h1, l0, l1;
-  pack_block(v, s, h0, h1, l0, l1);
-  if (FDMI_EPI_DBG == 1) {
-    asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1));
-    return;
-  }
-  if (FDMI_EPI_DBG == 3) {
-    store_lines_coalesced(blk, h0, h1, l0, l1);
-    return;
-  }
-  if (FDMI_EPI_DBG == 4) {  // ablation: unit-major within the wave's 32 rows (512 contiguous bytes per half-wave store)
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)blk), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)blk >> 32));
-    u32x4* g = reinterpret_cast<u32x4*>(((uintptr_t)hi << 32) | lo);
-    const int r = __lane_id() & 31;
-    g[(2 * half) * 32 + r] = h0;
-    g[(2 * half + 1) * 32 + r] = h1;
-    g[(4 + 2 * half) * 32 + r] = l0;
-    g[(5 + 2 * half) * 32 + r] = l1;
-    return;
-  }
-  if (pred) {
-    u32x4* u = reinterpret_cast<u32x4*>(blk) + 2 * half;
-    u[0] = h0;
-    u[1] = h1;
-    u[4] = l0;
-    u[5] = l1;
-  }
-}
-
-// The same into / from a GROUPED activation image: block cb of token row `row` (this lane pair's row)
 __device__ __forceinline__ void store_block_g(unsigned char* img, int nb, long long row, int cb, const float (&v)[16], float s, int half,
                                               bool pred) {
   u32x4 h0, h1, l0, l1;
@@ -184,37 +139,6 @@ __device__ __forceinline__ void store_block_g(unsigned char* img, int nb, long l
     *reinterpret_cast<u32x4*>(u0 + 4 * 512) = l0;
     *reinterpret_cast<u32x4*>(u0 + 5 * 512) = l1;
   }
-}
-
-// The same with the block's eight 16-byte units permuted: unit u is stored at u ^ sz (sz = (row >> 1) & 7 for the k rows,
-// which the attention kernel copies linearly into LDS and reads with 16-byte operand fetches: conflict free without
-// padding the rows to 144 bytes)
-__device__ __forceinline__ void store_block_swz(unsigned char* blk, const float (&v)[16], float s, int half, int sz) {
-  u32x4 h0, h1, l0, l1;
-  pack_block(v, s, h0, h1, l0, l1);
-  if (FDMI_EPI_DBG == 1) {
-    asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1), "v"(sz));
-    return;
-  }
-  if (FDMI_EPI_DBG == 3) {
-    store_lines_coalesced(blk, h0, h1, l0, l1);
-    return;
-  }
-  if (FDMI_EPI_DBG == 4) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)blk), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)blk >> 32));
-    u32x4* g = reinterpret_cast<u32x4*>(((uintptr_t)hi << 32) | lo);
-    const int r = __lane_id() & 31;
-    g[(2 * half) * 32 + r] = h0;
-    g[(2 * half + 1) * 32 + r] = h1;
-    g[(4 + 2 * half) * 32 + r] = l0;
-    g[(5 + 2 * half) * 32 + r] = l1;
-    return;
-  }
-  u32x4* u = reinterpret_cast<u32x4*>(blk);
-  u[(2 * half) ^ sz] = h0;
-  u[(2 * half + 1) ^ sz] = h1;
-  u[(4 + 2 * half) ^ sz] = l0;
-  u[(5 + 2 * half) ^ sz] = l1;
 }
 
 __device__ __forceinline__ float h2f_lo(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
@@ -263,59 +187,6 @@ __device__ __forceinline__ void load_group_block_raw(const unsigned char* blk0, 
   raw[1] = *reinterpret_cast<const u32x4*>(blk0 + (size_t)(off + 512));
   raw[2] = *reinterpret_cast<const u32x4*>(blk0 + (size_t)(off + 2048));
   raw[3] = *reinterpret_cast<const u32x4*>(blk0 + (size_t)(off + 2560));
-}
-
-// one block of a GROUPED activation image into quad layout
-__device__ __forceinline__ void load_block_g(const unsigned char* img, int nb, long long row, int cb, float (&v)[16], float inv_s, int half) {
-  const unsigned char* u0 = img + img_unit_offset(row, nb, cb, 2 * half);
-  const u32x4 raw[4] = {*reinterpret_cast<const u32x4*>(u0), *reinterpret_cast<const u32x4*>(u0 + 512),
-                        *reinterpret_cast<const u32x4*>(u0 + 4 * 512), *reinterpret_cast<const u32x4*>(u0 + 5 * 512)};
-  unpack_block(raw, v, inv_s);
-}
-
-// Load one block into quad layout: v[r] = (hi + lo) * inv_s   (row-major block at blk)
-__device__ __forceinline__ void load_block(const unsigned char* blk, float (&v)[16], float inv_s, int half) {
-  const u32x4* u = reinterpret_cast<const u32x4*>(blk) + 2 * half;
-  const u32x4 raw[4] = {u[0], u[1], u[4], u[5]};
-  unpack_block(raw, v, inv_s);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// "Normal" MFMA form (D = A W^T): lane (l31, half) owns COLUMN n = l31 of a 32-wide block and, in register r = 4q + e,
-// token row 8q + 4 half + e.  One register of a half-wave is therefore one row's 32 columns = one whole 128-byte block
-// [hi x32 | lo x32]: neighbouring lanes trade halves so that lane 2j holds the dword (hi 2j, hi 2j+1) of the hi plane and
-// lane 2j+1 the dword (lo 2j, lo 2j+1) of the lo plane, and ONE 4-byte store per lane writes two complete 128-byte lines
-// per wave instruction.  (The swapped form gives every lane its own row: sixteen-byte pieces of 64 different lines per
-// store instruction, and the L2 sees four times the write requests, each a partial line: measured 0.9 ms of an 8.2 ms
-// timestep, profiles/r02_gemm_ablation.log.)
-// byte offset of the lane's dword inside a block
-__device__ __forceinline__ int row_lane_offset(int l31) { return (l31 >> 1) * 4 + (l31 & 1) * 64; }
-// v_perm_b32 selectors (S0 = neighbour, S1 = own): even lane (own.lo16, nb.lo16), odd lane (nb.hi16, own.hi16)
-__device__ __forceinline__ unsigned row_pack_sel(int l31) { return (l31 & 1) ? 0x03020706u : 0x05040100u; }
-__device__ __forceinline__ unsigned dpp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
-// xs = value * scale of column n  ->  the dword this lane stores at row_lane_offset()
-__device__ __forceinline__ unsigned row_dword(float xs, unsigned sel) {
-  const _Float16 hi = (_Float16)xs;
-  const _Float16 lo = (_Float16)(xs - (float)hi);
-  const unsigned own = pack_h2(hi, lo);
-  return __builtin_amdgcn_perm(dpp_xor1(own), own, sel);
-}
-// the dword read at row_lane_offset() of a block  ->  (hi + lo) of column n, unscaled.
-// even lane holds (hi n, hi n+1): keeps lo16, gives hi16; odd lane holds (lo n-1, lo n): keeps hi16, gives lo16
-__device__ __forceinline__ float row_value(unsigned d, int l31) {
-  const unsigned arranged = (l31 & 1) ? ((d >> 16) | (d << 16)) : d;  // keep in lo16, give in hi16
-  const float keep = h2f_lo(arranged), give = h2f_hi(arranged);
-  return keep + __builtin_bit_cast(float, dpp_xor1(__builtin_bit_cast(unsigned, give)));
-}
-// sum over the 32 lanes of each half-wave; the total is valid in lanes 16-31 / 48-63
-__device__ __forceinline__ float half_wave_sum(float x) {
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));  // row_mirror
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false)); // row_bcast15 into rows 1, 3
-  return x;
 }
 
 }  // namespace fdmi
