@@ -212,11 +212,13 @@ static void launch_t(const float* qkv, const float* demb, const int* lens, float
                      hipStream_t s) {
   constexpr int LP = 32 * T;
   const size_t smem = sizeof(float) * (HPB * LP * KLD + HPB * LP * 32 + (REL ? 2 * LP * KLD : 0) + 4 * HPB * 32 * KLD);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};  // the attribute is per device (one model per device in a multi-GPU process)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<T, REL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int hgroups = (H + HPB - 1) / HPB;
   hipLaunchKernelGGL((attn_f32_kernel<T, REL>), dim3(B * hgroups), dim3(256 * HPB), smem, s, qkv, demb, lens, ctx, L, H,

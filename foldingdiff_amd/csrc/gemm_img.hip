@@ -48,6 +48,9 @@ template <int V> using IC = std::integral_constant<int, V>;
 #ifndef FDMI_NL
 #define FDMI_NL 2
 #endif
+#ifndef FDMI_G6FIRST
+#define FDMI_G6FIRST 1  // the wm 1 waves run MFMA group 6 before their first-fragment reads (0: every wave reads first); -0.6 % per timestep
+#endif
 constexpr int NL = FDMI_NL;                                      // loader waves (1, 2 or 4)
 constexpr int BM = 128, BN = 384, NTHR = 64 * (8 + NL);         // 8 compute waves + NL loader waves
 constexpr int W_STAGE = BN * 128, A_STAGE = BM * 128;           // bytes per k-tile stage
@@ -514,13 +517,29 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       FD_STAMP(0);
       groups_1_to_5(SW);
       FD_STAMP(1);
+#if FDMI_G6FIRST
+      FD_WAIT_LGKM0();  // (the same wait as inside the barrier, but visible to the compiler's counter model: no waits in group 6)
+#endif
       barrier_keep_vm();  // every fragment of this position is in registers: its slots are free; the next position landed
       FD_STAMP(2);
+#if FDMI_G6FIRST
+      // Behind the barrier all eight waves want the LDS for their first fragments at once (~300 cycles during which no
+      // wave issues a matrix instruction).  The two waves of a SIMD are (wm 0, wm 1): the wm 1 wave runs group 6 first --
+      // it needs registers only -- and fetches afterwards, under the other wave's group 6.
+      if (wm == 0) first_fragments();
+      FD_SB();
+      FD_STAMP(3);
+      mm6(SW, wl1, ah1);
+      FD_SB();
+      if (wm != 0) first_fragments();
+      FD_SB();
+#else
       first_fragments();
       FD_SB();  // reads first: they fly while group 6 runs
       FD_STAMP(3);
       mm6(SW, wl1, ah1);
       FD_SB();
+#endif
       FD_STAMP(4);
       ++slot;
     }
