@@ -30,9 +30,10 @@
 //    statistics are in-lane sums, and a block is written with four 16-byte stores per lane after a half-wave register
 //    exchange (img_common.h); the grouped image layout makes each of those stores 512 contiguous bytes per half-wave.
 //  What bounds it (profiles/r02_gemm_ablation.log, r02_probes.log): MFMA and VALU instructions of different waves do NOT
-//  overlap on a SIMD (co-issue probe), so epilogue arithmetic adds to the matrix time; and when all 256 CUs store at once
-//  the chip takes ~5.4 TB/s = 10 B/clk per CU (one CU alone: 72 B/clk), so every tile's 196 KiB burst costs ~9 us during
-//  which the CU's loads queue behind its stores.
+//  overlap on a SIMD (co-issue probe), so epilogue arithmetic adds to the matrix time; the k-loop runs at ~2900 cycles per
+//  k-tile for 2304 matrix cycles; and the outputs' HBM writes cost ~1.8 ms of a 7.7 ms timestep.  That last cost is the
+//  traffic itself, not a chip-wide store burst: with the workgroups' start times spread over a tile period a tile costs the
+//  same (de-phase probe, third part of the ablation log).
 #include <cstdlib>
 #include <type_traits>
 
