@@ -5,10 +5,13 @@ Mirrors the functions ``bin/sample.py`` calls after ``sampling.sample``
 (``write_preds_pdb_folder`` bin/sample.py:105-128 -> ``create_new_chain_nerf``
 foldingdiff/angles_and_coords.py:112-184 -> ``write_coords_to_pdb`` :187-253), with the coordinates
 of ALL chains built by one ``fd_nerf`` launch instead of a multiprocessing pool of per-residue
-Python loops.  The PDB text follows the fixed-column ATOM record the reference gets from
-biotite 0.34's ``PDBFile`` (chain A, GLY residues, N / CA / C, occupancy 1.00, B-factor 5.00, no
-CONECT records because no atom is a hetero atom).  biotite is not installable offline, so the byte
-layout is restated from the PDB format specification, not pinned against biotite's output.
+Python loops.  The PDB text is what the reference gets from biotite 0.34's ``PDBFile`` for the structure it
+builds (chain A, GLY residues, N / CA / C, occupancy 1.00, B-factor 5.00, every consecutive atom pair bonded):
+80-column ATOM records, then one CONECT record per direction for each bond that joins two residues (C of
+residue i -- N of residue i + 1; biotite leaves the bonds inside a residue to the residue template).  The byte
+layout is pinned against a file the reference's own ``write_coords_to_pdb`` wrote
+(``plots/pdb_structures/noising_visualization/fully_noised.pdb`` -> tests/golden/ref_written_backbone.pdb,
+tests/test_host.py).
 The angle CSVs of bin/sample.py:365-369 are plain ``DataFrame.to_csv`` calls on the arrays
 ``sampling.sample`` returns and need no counterpart here.
 """
@@ -58,6 +61,9 @@ def write_coords_to_pdb(coords: np.ndarray, out_fname: str) -> str:
         lines.append(
             f"ATOM  {((j % 99999) + 1):>5d} {atom_field} GLY A{((j // 3) % 9999 + 1):>4d}    "
             f"{x:>8.3f}{y:>8.3f}{z:>8.3f}{1.0:>6.2f}{5.0:>6.2f}          {element:>2}  ")
+    for c in range(3, len(coords), 3):   # peptide bonds: atom ids c (C) and c + 1 (N of the next residue), both directions
+        lines.append(f"CONECT{c:>5d}{c + 1:>5d}")
+        lines.append(f"CONECT{c + 1:>5d}{c:>5d}")
     with open(out_fname, "w") as fh:
         fh.write("\n".join(lines) + "\n")
     return out_fname

@@ -250,7 +250,8 @@ def test_pdb_writer_fixed_columns(tmp_path):
     coords = rng.standard_normal((3 * 130, 3)) * 40
     f = ac.write_coords_to_pdb(coords, str(tmp_path / "x.pdb"))
     lines = open(f).read().splitlines()
-    assert len(lines) == 390 and all(len(l) == 80 for l in lines)
+    assert len(lines) == 390 + 2 * 129 and all(len(l) == 80 for l in lines[:390])
+    assert lines[390] == "CONECT    3    4" and lines[391] == "CONECT    4    3" and lines[-1] == "CONECT  388  387"
     l = lines[4]  # second residue, CA
     assert l[:6] == "ATOM  " and int(l[6:11]) == 5 and l[12:16] == " CA " and l[17:20] == "GLY" and l[21] == "A"
     assert int(l[22:26]) == 2 and l[54:60] == "  1.00" and l[60:66] == "  5.00" and l[76:78] == " C"
@@ -258,6 +259,11 @@ def test_pdb_writer_fixed_columns(tmp_path):
     assert np.abs(ac.read_pdb_backbone(f) - coords).max() <= 5.001e-4
     with pytest.raises(AssertionError):
         ac.write_coords_to_pdb(coords[:4], str(tmp_path / "y.pdb"))
+    # byte layout pinned against a file written by the reference's own write_coords_to_pdb through biotite
+    # (tests/golden/make_golden_pdb.py): same coordinates in -> the same bytes out, ATOM and CONECT records
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_written_backbone.pdb")
+    g = ac.write_coords_to_pdb(ac.read_pdb_backbone(gold), str(tmp_path / "g.pdb"))
+    assert open(g, "rb").read() == open(gold, "rb").read()
     # column selection rules of create_new_chain_nerf (no device needed until the build)
     vals, keep = ac._select(np.zeros((3, 4), np.float32), ["phi", "psi", "omega", "0C:1N"], None, None)
     assert keep == ["phi", "psi", "omega", "0C:1N"]
