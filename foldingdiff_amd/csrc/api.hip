@@ -1326,7 +1326,6 @@ int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, con
   }
   float *dA = nullptr, *dW = nullptr, *db = nullptr, *dr = nullptr, *dC = nullptr;
   void* dWp = nullptr;
-  float wscale = 1.f;
   int rc = FD_OK;
   auto cleanup = [&]() {
     for (void* p : {(void*)dA, (void*)dW, (void*)db, (void*)dr, (void*)dC, dWp})

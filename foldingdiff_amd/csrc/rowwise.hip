@@ -14,8 +14,6 @@
 
 namespace fdmi {
 
-constexpr int kMaxJ = 16;  // d_model <= 64 * kMaxJ
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
