@@ -271,3 +271,53 @@ def test_pdb_writer_fixed_columns(tmp_path):
         ac._select(np.zeros((3, 4), np.float32), ["phi", "psi", "omega", "chi1"], None, None)
     with pytest.raises(AssertionError):
         ac._select(np.zeros((3, 2), np.float32), ["phi", "psi"], None, None)
+
+
+def test_f16x3_split_arithmetic_is_fp32_class():
+    """The default contraction arithmetic restated in numpy (csrc/gemm_img.hip header, csrc/img_common.h: x*s = hi + lo
+    with hi = fp16(x*s), lo = fp16(x*s - hi); a product is a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, exact in fp32, summed in
+    fp32): against float64 it must sit in the error class of an fp32 GEMM for the shapes and value ranges of the path,
+    an operand must be represented to 2^-22 relative, and the power-of-two scales of api.hip (bound * s <= 30000)
+    must keep every hi finite.  No GPU: this pins the CLAIM; tests/test_gpu_parity.py measures the kernel."""
+    rng = np.random.default_rng(0)
+    f16, f32, f64 = np.float16, np.float32, np.float64
+
+    def scale_for(bound):                       # api.hip: scale_for
+        return f32(2.0 ** np.clip(np.floor(np.log2(30000.0 / bound)), -40, 40))
+
+    def split(x, s):
+        xs = (x.astype(f32) * s).astype(f32)
+        hi = xs.astype(f16)
+        lo = (xs - hi.astype(f32)).astype(f16)
+        return hi, lo
+
+    def gemm_split(a, w, sa, sw):
+        ah, al = split(a, sa)
+        wh, wl = split(w, sw)
+        acc = np.zeros((a.shape[0], w.shape[0]), f32)
+        for k0 in range(0, a.shape[1], 16):     # one v_mfma_f32_32x32x16_f16 step: products exact, fp32 accumulate
+            sl = slice(k0, k0 + 16)
+            for x, y in ((ah, wh), (ah, wl), (al, wh)):
+                acc = (acc + (x[:, sl].astype(f64) @ y[:, sl].astype(f64).T).astype(f32)).astype(f32)
+        return acc * f32(1.0 / (sa * sw))
+
+    for K, act_scale, w_std in ((384, 1.0, 0.02), (768, 0.6, 0.02), (384, 4.0, 0.3)):
+        a = (rng.standard_normal((64, K)) * act_scale).astype(f32)
+        a[3, 5] = 19.0 * act_scale              # LayerNorm outputs reach a large multiple of their typical size
+        w = (rng.standard_normal((96, K)) * w_std).astype(f32)
+        sa = scale_for(np.abs(a).max() * 1.5)   # any valid bound works; the real one is gamma sqrt(d) + beta
+        sw = f32(2.0 ** np.floor(np.log2(16383.0 / np.abs(w).max())))   # api.hip: max|w| * scale in [8192, 16384)
+        hi, lo = split(a, sa)
+        assert np.isfinite(hi.astype(f32)).all() and np.abs(hi.astype(f32)).max() <= 30000.0 * 1.001
+        ref = a.astype(f64) @ w.astype(f64).T
+        got = gemm_split(a, w, sa, sw)
+        plain = a @ w.T                          # numpy's fp32 GEMM (pairwise / blocked fp32 accumulation)
+        rms = np.sqrt(np.mean(ref ** 2))
+        err_split = np.sqrt(np.mean((got - ref) ** 2)) / rms
+        err_plain = np.sqrt(np.mean((plain.astype(f64) - ref) ** 2)) / rms
+        assert err_split <= 4e-7, (K, err_split)                       # measured 1.8e-7 .. 2.4e-7 (GPU kernel: 2.4e-7)
+        assert err_split <= 1.5 * err_plain, (K, err_split, err_plain)  # numpy's fp32 GEMM: 3.5e-7
+        # representation error of one operand: hi + lo carry 22 bits, rounded to nearest
+        back = (hi.astype(f64) + lo.astype(f64)) / f64(sa)
+        big = np.abs(a) > np.abs(a).max() * 2.0 ** -10
+        assert (np.abs(back - a)[big] / np.abs(a)[big]).max() <= 2.0 ** -22
