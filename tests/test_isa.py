@@ -1,0 +1,88 @@
+"""
+Static guard on the hot GEMM kernel's code generation (no GPU: hipcc cross-compiles gfx950 to assembly).
+
+Parity tests cannot see a register spill, but a spill inside the k-loop of ``gi::gemm_img_kernel`` costs more than
+most optimisations gain (a scratch reload is a vector-memory operation: ~500 cycles with every wave of the workgroup
+idle, and behind an epilogue's stores it waits for all of them).  This pins what the round-2 tree achieves
+(profiles/r02_gemm_img_isa.txt) so that a later change that makes hipcc spill again fails loudly.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+from foldingdiff_amd import build as fbuild
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPI = {0: "GELU", 1: "LN", 2: "QK", 3: "VT", 4: "BIAS", 5: "QKV"}
+# scratch bytes per work-item the production (non-PROF) instantiations may use: the epilogues of the LayerNorm and the
+# merged q|k|v kernels spill a few dwords OUTSIDE the k-loop bodies; everything else must be spill-free
+MAX_SCRATCH = {0: 0, 1: 32, 2: 0, 3: 0, 4: 0, 5: 52}
+
+
+@pytest.fixture(scope="module")
+def gemm_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "gemm_img.s"
+    cmd = [fbuild.find_hipcc(), "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include"),
+           "-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, "gemm_img.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+def _kernels(asm):
+    """{(epi, prof): body text} of the gemm_img_kernel instantiations, and their .amdhsa metadata."""
+    bodies, meta = {}, {}
+    for m in re.finditer(r"^(_ZN4fdmi2gi15gemm_img_kernelILi(\d)ELb[01]ELb([01])ELi0EEEvNS_11GemmImgArgsE):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm,
+                         re.S | re.M):
+        bodies[(int(m.group(2)), int(m.group(3)))] = m.group(4)
+    for m in re.finditer(r"\.name:\s+_ZN4fdmi2gi15gemm_img_kernelILi(\d)ELb[01]ELb([01])ELi0EEEvNS_11GemmImgArgsE\n(.*?)\.wavefront_size",
+                         asm, re.S):
+        fields = dict(re.findall(r"\.(\w+):\s+(\d+)", m.group(3)))
+        meta[(int(m.group(1)), int(m.group(2)))] = {k: int(v) for k, v in fields.items()}
+    return bodies, meta
+
+
+def test_production_gemm_kernels_stay_within_their_scratch_budget(gemm_asm):
+    bodies, meta = _kernels(gemm_asm)
+    assert sorted(k[0] for k in meta if k[1] == 0) == sorted(EPI), sorted(meta)
+    for (epi, prof), md in sorted(meta.items()):
+        if prof:
+            continue  # the stamp-recording instantiations are debug builds
+        assert md["vgpr_count"] <= 168, (EPI[epi], md)   # 10 waves per workgroup: three waves on a SIMD share 512 registers
+        assert md["private_segment_fixed_size"] <= MAX_SCRATCH[epi], (EPI[epi], md)
+
+
+def test_k_loops_hold_no_scratch_and_no_vector_memory_wait(gemm_asm):
+    """The steady-state k-loop body (30 MFMAs, barrier, 6 MFMAs, backward branch) of every production instantiation:
+    no scratch instruction, no s_waitcnt vmcnt (the compute waves have no vector-memory operation in flight there)."""
+    bodies, _ = _kernels(gemm_asm)
+    assert sorted(k[0] for k in bodies if k[1] == 0) == sorted(EPI), sorted(bodies)
+    for (epi, prof), text in sorted(bodies.items()):
+        if prof:
+            continue
+        lines = text.splitlines()
+        loops = 0
+        label_at = {m.group(1): k for k, l in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+        for i, ln in enumerate(lines):
+            if "Inner Loop Header" not in ln:
+                continue
+            # the loop = the header block down to the first BACKWARD branch behind it, plus the latch block that branch
+            # targets (hipcc rotates the k-loop: the latch sits in front of the header and falls through into it)
+            j = next((k for k in range(i + 1, len(lines))
+                      for m in [re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", lines[k])] if m and label_at.get(m.group(1), 1 << 30) <= i), None)
+            if j is None:
+                continue
+            tgt = label_at[re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", lines[j]).group(1)]
+            body = lines[tgt:j + 1]
+            if sum("v_mfma" in b for b in body) < 36:
+                continue   # (parameter / loader loops)
+            loops += 1
+            assert not any("scratch_" in b for b in body), (EPI[epi], [b for b in body if "scratch_" in b])
+            waits = [b.strip() for b in body if re.search(r"s_waitcnt vmcnt\(\d+\)", b)]
+            # known and tolerated for now: the q|k and the merged q|k|v kernels carry ONE wait per loop, a register-reuse guard
+            # for the row-info prefetch (global loads) of the previous tile -- satisfied at once in steady state, but in a tile's
+            # first k-tile it also waits for the previous epilogue's stores (scripts/candidates/0002 removes the loads)
+            assert len(waits) <= (1 if epi in (2, 5) else 0), (EPI[epi], waits)
+        assert loops >= 1, EPI[epi]
