@@ -1,7 +1,10 @@
 """
 Build libfdmi.so (the gfx950 HIP kernels + C ABI) in-tree with hipcc.
 
-    python -m foldingdiff_amd.build [--force] [variant DEFINE[=VALUE] ...]
+    python -m foldingdiff_amd.build [--force] [variant DEFINE[=VALUE] | @source=-flag ...]
+
+An experiment argument of the form ``@gemm_img=-fno-slp-vectorize`` adds a compiler flag for that one source
+(``@all=...`` for every source).
 
 hipcc cross-compiles for gfx950 without a GPU present.  The shared object lands in
 foldingdiff_amd/_lib/ (git-ignored, shipped to the GPU box with the tree).
@@ -21,6 +24,8 @@ SOURCES = ["api.hip", "gemm_f32.hip", "gemm_img.hip", "attention_f32.hip", "atte
 HEADERS = [os.path.join(CSRC, "fdmi_kernels.h"), os.path.join(CSRC, "img_common.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "fdmi.h")]
 ARCH = "gfx950"
+# flags of single sources (see the header of the source for the reason)
+PER_SOURCE_FLAGS = {}
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 
@@ -55,7 +60,10 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
         op = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + HEADERS):
-            jobs.append([hipcc] + CXXFLAGS + [f"-D{d}" for d in defines] + ["-c", sp, "-o", op])
+            stem = src.replace(".hip", "")
+            extra = [d.split("=", 1)[1] for d in defines if d.startswith("@") and d[1:].split("=", 1)[0] in (stem, "all")]
+            jobs.append([hipcc] + CXXFLAGS + PER_SOURCE_FLAGS.get(stem, []) + extra
+                        + [f"-D{d}" for d in defines if not d.startswith("@")] + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
