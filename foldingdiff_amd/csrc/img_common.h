@@ -141,6 +141,17 @@ __device__ __forceinline__ void store_block_g(unsigned char* img, int nb, long l
   }
 }
 
+// fp16 half of a packed pair times an fp32 factor plus an fp32 addend in ONE instruction (v_fma_mix_f32): exact product, one rounding
+__device__ __forceinline__ float fma_mix_lo(unsigned hpair, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned hpair, float b, float c) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ float h2f_lo(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
 __device__ __forceinline__ float h2f_hi(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
 
@@ -189,4 +200,53 @@ __device__ __forceinline__ void load_group_block_raw(const unsigned char* blk0, 
   raw[3] = *reinterpret_cast<const u32x4*>(blk0 + (size_t)(off + 2560));
 }
 
+// ---- exact-erf GELU of the GEMM epilogues (HF "gelu", modelling.py:195-196 / BertIntermediate)
+__device__ __forceinline__ float erf_rational(float x) {  // (13,8) rational minimax on [-4,4], |err| <= 4.5e-7 (tests/test_host.py)
+  x = __builtin_fminf(__builtin_fmaxf(x, -4.0f), 4.0f);
+  const float x2 = x * x;
+  float p = -2.72614225801306e-10f;
+  p = __builtin_fmaf(p, x2, 2.77068142495902e-08f);
+  p = __builtin_fmaf(p, x2, -2.10102402082508e-06f);
+  p = __builtin_fmaf(p, x2, -5.69250639462346e-05f);
+  p = __builtin_fmaf(p, x2, -7.34990630326855e-04f);
+  p = __builtin_fmaf(p, x2, -2.95459980854025e-03f);
+  p = __builtin_fmaf(p, x2, -1.60960333262415e-02f);
+  float q = -1.45660718464996e-05f;
+  q = __builtin_fmaf(q, x2, -2.13374055278905e-04f);
+  q = __builtin_fmaf(q, x2, -1.68282697438203e-03f);
+  q = __builtin_fmaf(q, x2, -7.37332916720468e-03f);
+  q = __builtin_fmaf(q, x2, -1.42647390514189e-02f);
+  return (p * x) * __builtin_amdgcn_rcpf(q);
+}
+__device__ __forceinline__ float gelu_erf(float x) {  // HF "gelu": 0.5 x (1 + erf(x / sqrt 2))
+  const float h = 0.5f * x;
+  return __builtin_fmaf(h, erf_rational(x * 0.70710678118654752440f), h);
+}
+
+// the same arithmetic on element pairs (v_pk_fma_f32 / v_pk_mul_f32 for every step but the clamp and the reciprocal): the same
+// operations in the same order per element, hence the same bits.  Only for epilogues that run with the matrix pipe idle
+// (gemm_img.hip): packed fp32 instructions serialize with another wave's MFMAs (profiles/r03_coissue2_probe.log)
+typedef float gf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gf2 gelu_erf2(gf2 x) {
+  const gf2 h = x * 0.5f;
+  gf2 y = x * 0.70710678118654752440f;
+  y = __builtin_elementwise_min(__builtin_elementwise_max(y, gf2{-4.0f, -4.0f}), gf2{4.0f, 4.0f});
+  const gf2 y2 = y * y;
+  auto c = [](float v) { return gf2{v, v}; };
+  gf2 p = c(-2.72614225801306e-10f);
+  p = __builtin_elementwise_fma(p, y2, c(2.77068142495902e-08f));
+  p = __builtin_elementwise_fma(p, y2, c(-2.10102402082508e-06f));
+  p = __builtin_elementwise_fma(p, y2, c(-5.69250639462346e-05f));
+  p = __builtin_elementwise_fma(p, y2, c(-7.34990630326855e-04f));
+  p = __builtin_elementwise_fma(p, y2, c(-2.95459980854025e-03f));
+  p = __builtin_elementwise_fma(p, y2, c(-1.60960333262415e-02f));
+  gf2 q = c(-1.45660718464996e-05f);
+  q = __builtin_elementwise_fma(q, y2, c(-2.13374055278905e-04f));
+  q = __builtin_elementwise_fma(q, y2, c(-1.68282697438203e-03f));
+  q = __builtin_elementwise_fma(q, y2, c(-7.37332916720468e-03f));
+  q = __builtin_elementwise_fma(q, y2, c(-1.42647390514189e-02f));
+  const gf2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  const gf2 e = (p * y) * r;
+  return __builtin_elementwise_fma(h, e, h);
+}
 }  // namespace fdmi

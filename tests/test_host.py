@@ -161,13 +161,13 @@ def test_step_noise_draw_order_matches_reference():
 
 
 def test_gelu_rational_erf_accuracy():
-    """The fp16x3 GEMM epilogue evaluates erf as a rational function (csrc/gemm_img.hip:erf_rational,
+    """The fp16x3 GEMM epilogue evaluates erf as a rational function (csrc/img_common.h:erf_rational,
     coefficients restated here): it must stay in libm-erff's error class against float64 erf, and the
     GELU built on it within torch's own fp32 GELU error (the exact-erf "gelu" of modelling.py:195-196)."""
     import math
     import re
     f = np.float32
-    src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "gemm_img.hip")).read()
+    src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "img_common.h")).read()
     body = src[src.index("float erf_rational(float x)"):src.index("float gelu_erf(float x)")]
     consts = [f(c) for c in re.findall(r"(-?\d\.\d+e-\d+)f", body)]
     assert len(consts) == 12, consts            # 7 numerator + 5 denominator coefficients, in evaluation order

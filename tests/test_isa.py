@@ -16,9 +16,9 @@ from foldingdiff_amd import build as fbuild
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EPI = {0: "GELU", 1: "LN", 2: "QK", 3: "VT", 4: "BIAS", 5: "QKV"}
-# scratch bytes per work-item the production (non-PROF) instantiations may use: the epilogues of the LayerNorm and the
-# merged q|k|v kernels spill a few dwords OUTSIDE the k-loop bodies; everything else must be spill-free
-MAX_SCRATCH = {0: 0, 1: 32, 2: 0, 3: 0, 4: 0, 5: 52}
+# scratch bytes per work-item the production (non-PROF) instantiations may use: none since round 3 (four fragment buffers,
+# row info through LDS, half-block residual reads through buffer descriptors)
+MAX_SCRATCH = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0}
 
 
 @pytest.fixture(scope="module")
@@ -81,8 +81,5 @@ def test_k_loops_hold_no_scratch_and_no_vector_memory_wait(gemm_asm):
             loops += 1
             assert not any("scratch_" in b for b in body), (EPI[epi], [b for b in body if "scratch_" in b])
             waits = [b.strip() for b in body if re.search(r"s_waitcnt vmcnt\(\d+\)", b)]
-            # known and tolerated for now: the q|k, v^T and merged q|k|v kernels carry ONE wait per loop, a register-reuse guard
-            # for the row-info prefetch (global loads) of the previous tile -- satisfied at once in steady state, but in a tile's
-            # first k-tile it also waits for the previous epilogue's stores (scripts/candidates/0002 removes the loads)
-            assert len(waits) <= (1 if epi in (2, 3, 5) else 0), (EPI[epi], waits)
+            assert len(waits) == 0, (EPI[epi], waits)   # (round 2 tolerated one in the q|k / v^T kernels: the row info now lands in LDS)
         assert loops >= 1, EPI[epi]
