@@ -23,6 +23,8 @@ The JSON line also carries
   cpu_baseline  the reference CPU path (oracle restatement, "port") timed on this box's
                 host cores over a bounded sample of the same workload.
   extras.c5     one pass of BASELINE config C5 (L = 512, batch 128, max_position_embeddings = 512).
+  extras.c3     BASELINE config C3 through sampling.sample (the reference's published setting), Philox and default noise.
+  extras.host_entry  p_sample_loop with host buffers in / out at C2, both noise modes.
 """
 import argparse
 import ctypes as C
@@ -35,6 +37,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 RELEASED = dict(hidden_size=384, num_attention_heads=12, intermediate_size=768, num_hidden_layers=12,
@@ -58,47 +61,59 @@ def flops_per_token(L, d=384, ff=768, layers=12, F=6):
     return layers * (8 * d * d + 4 * d * ff + 6 * L * d) + 2 * F * d + 2 * d * d + 2 * d * F
 
 
-def cpu_baseline(B, L, T, shape, steps=3):
-    """Reference CPU path (oracle port of foldingdiff/sampling.py p_sample_loop + the restated BertForDiffusion), host
-    cores of this box, on a bounded sample of the SAME workload: `steps` consecutive reverse steps at the
-    full batch, extrapolated to T steps (steps are homogeneous: same kernels, same shapes, t only indexes tables)."""
+def cpu_baseline(B, L, T, shape, steps=10, check_batch=8):
+    """Reference CPU path (oracle port of foldingdiff/sampling.py p_sample_loop + the restated BertForDiffusion) on the host
+    cores of this box, SURVEY 8(d)'s protocol: K = `steps` consecutive reverse steps at the full batch, extrapolated to T
+    steps (steps are homogeneous: same kernels, same shapes, t only indexes tables), with the torch thread count probed ON
+    THE FULL BATCH (the probe steps are part of the K), plus one complete T-step run at batch `check_batch` as the
+    linearity check of that extrapolation."""
     from oracle import ref_model, ref_sampling
 
     model = ref_model.synthetic_model(ref_model.OracleConfig(**shape), seed=0, perturb=False)
     betas = ref_sampling.beta_schedule("cosine", T)
     torch.manual_seed(0)
 
-    def run(nsteps, batch):
-        img = ref_sampling.initial_noise((batch, L, 6), [True] * 6)
+    def run(t_hi, nsteps, img, batch):
         lens = [L] * batch
         t0 = time.perf_counter()
-        for i in reversed(range(T - nsteps, T)):
+        for i in reversed(range(t_hi - nsteps + 1, t_hi + 1)):
             img = ref_sampling.p_sample(model, img, torch.full((batch,), i, dtype=torch.long), lens, betas)
             img = ref_sampling.wrap(img, -torch.pi, torch.pi)
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, img
 
-    # torch intra-op threads: all logical CPUs is rarely the fastest setting on a 2-socket SMT host (and a container may
-    # be cgroup-limited); probe a few counts on one step of a 1/8 batch and keep the best
     ncpu = os.cpu_count() or 1
-    cand = sorted({c for c in (16, 32, 64, ncpu) if c <= ncpu})
-    best, cores = None, cand[0]
-    pb = max(8, B // 8)
-    for c in cand:
+    cand = sorted({c for c in (16, 32, 64, 128, ncpu) if c <= ncpu})
+    img = ref_sampling.initial_noise((B, L, 6), [True] * 6)
+    t_next, probe, times = T - 1, {}, []
+    for c in cand:  # one full-batch step per candidate thread count (all logical CPUs is rarely the fastest on an SMT host)
         torch.set_num_threads(c)
-        run(1, pb)
-        dt = run(1, pb)
-        if best is None or dt < best:
-            best, cores = dt, c
+        dt, img = run(t_next, 1, img, B)
+        probe[c] = dt
+        t_next -= 1
+        if dt > 1.5 * min(probe.values()):  # past the knee: larger counts only get slower (256 threads: 64 s per step here)
+            break
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    per_step = run(steps, B) / steps
+    rest = max(steps - len(probe), 1)
+    dt, img = run(t_next, rest, img, B)
+    per_step = dt / rest                                  # steps at the chosen thread count only
+    # linearity check: a complete T-step run at a small batch against its own first `steps` steps x T / steps
+    small = ref_sampling.initial_noise((check_batch, L, 6), [True] * 6)
+    k_dt, small = run(T - 1, steps, small, check_batch)
+    full_dt, _ = run(T - 1 - steps, T - steps, small, check_batch)
+    full_dt += k_dt
     return {
         "value": B / (per_step * T),
         "unit": "backbones/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{steps} consecutive reverse steps (t = {T - 1} .. {T - steps}) at the full batch {B}, L={L} (of T={T}), torch fp32 "
-                  f"eval-mode oracle, extrapolated x{T}/{steps}; {per_step * 1e3:.0f} ms/step; best of torch thread counts {cand} "
-                  f"(probed on batch {pb}) on {ncpu} logical CPUs",
+        "sample": f"K={steps} consecutive reverse steps from t={T - 1} at the full batch {B}, L={L} (of T={T}), torch fp32 eval-mode "
+                  f"oracle: one step per candidate thread count of {cand} until past the knee ({', '.join(f'{c}: {v:.1f} s' for c, v in probe.items())}), "
+                  f"the other {rest} at the best ({cores} threads): {per_step * 1e3:.0f} ms/step, extrapolated x{T}; "
+                  f"{ncpu} logical CPUs",
+        "linearity_check": {"batch": check_batch, "full_T_seconds": full_dt, "first_K_steps_seconds": k_dt,
+                            "extrapolated_seconds": k_dt * T / steps, "ratio_full_over_extrapolated": full_dt / (k_dt * T / steps),
+                            "backbones_per_s": check_batch / full_dt},
     }
 
 
@@ -113,6 +128,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default: the configuration's)")
     ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--no-c5-extra", action="store_true", help="skip the extra BASELINE C5 pass reported in extras (N=1, c2 only)")
+    ap.add_argument("--no-user-paths", action="store_true",
+                    help="skip extras.c3 (sampling.sample on the manuscript sweep, both noise modes) and extras.host_entry (N=1, c2 only)")
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--profile-every", type=int, default=100)
     ap.add_argument("--no-history", action="store_true", help="do not keep the [T,B,L,F] history in HBM")
@@ -241,6 +258,7 @@ def main():
             "kernel": pinfo["kernel"],
             "bound": "mfma", "achieved": dom["tflops"], "peak": pinfo["peak"], "unit": "TFLOP/s",
             "frac": dom["tflops"] / pinfo["peak"], "traffic": traffic if (B, L) == (512, 128) else None,
+            "traffic_static": True,  # read from profiles/traffic.json (separate rocprofv3 --pmc passes of this command), not from this run
             "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "flops_per_launch": dom["flops"],
             "algorithmic_bytes_per_launch": dom["bytes"],
         }
@@ -272,12 +290,18 @@ def main():
                        "mfma_floor_ms": flops_per_token(L) * L * B * mfma_mult / (pinfo["peak"] * 1e12) * 1e3,
                        "hbm_achieved_gbs": hbm_bytes_step / (ms_step * 1e-3) / 1e9,
                        "note": "floors: HBM at the achievable 6.3 TB/s (8 TB/s peak), MFMA at the dense peak of the instruction "
-                               "used (3 MFMAs per product in f16x3).  Neither floor shows what the probes measured (profiles/r02_probes.log): "
-                               "MFMA and VALU instructions serialize per SIMD, the k-loops run at ~2900 cycles per 2304 matrix cycles, and the "
-                               "tile epilogues' HBM writes are not overlapped with matrix work"},
+                               "used (3 MFMAs per product in f16x3; a dense MFMA stream on random operands clocks the chip at ~1.6 GHz, "
+                               "profiles/r03_clock_probe.log, so the sustained matrix peak is ~2/3 of the 2.4 GHz figure).  Neither floor shows what "
+                               "the probes measured: the GEMM k-loops are bound by the per-CU L2 -> LDS ingest (~2900 cycles per 2304 matrix "
+                               "cycles), and the tile epilogues (VALU + the outputs' HBM writes) run with the matrix pipe idle"},
         "roofline": roofline,
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
                         "launches": v["launches"]} for k, v in kernels.items()},
+        # the HBM-bound row kernels north_star singles out: algorithmic bytes / measured launch time against the 8 TB/s peak
+        "row_kernels_hbm": {k: {"avg_us": round(kernels[k]["avg_ms"] * 1e3, 1), "gbs": round(kernels[k]["gbs"], 1),
+                                "frac_of_8TBs": round(kernels[k]["gbs"] / PEAK_HBM_GBS, 3)}
+                            for k in ("embed_ln_time", "head_update_wrap") if k in kernels},
+        "dist": {"backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1},
     }
     if world == 1 and model.precision != "f32" and not args.no_exact_f32 and L <= 128:
         # the same workload with every contraction on v_mfma_f32_32x32x2_f32 (bitwise-fp32 products), one pass
@@ -313,6 +337,45 @@ def main():
                                    "ms_per_timestep": dt5 / T * 1e3, "passes": 1,
                                    "algorithmic_tflops": 128 / dt5 * flops_per_token(512) * 512 * T / 1e12}}
         del m5
+    if world == 1 and args.config == "c2" and not args.no_user_paths and (B, L) == (512, 128):
+        # what users call.  (a) BASELINE C3, the reference's own published setting (README.md:100-103, bin/sample.py defaults):
+        # sampling.sample(n=10, sweep_lengths=(50, 128), batch_size=512) -- 780 backbones in two chunks, packed rows --
+        # with on-device Philox noise and in the DEFAULT mode (the reference's torch.randn order, streamed from the host).
+        # Useful tokens only: padded positions are not work.  (b) the host entry the metric is defined on:
+        # p_sample_loop with host x_init in / final angles out (fd_sample_ex, PCIe both ways) at C2, both noise modes.
+        model.set_precision(pinfo_key)
+        model.prepare(betas)
+        _binding.check(lib.fd_profile_every(model._handle, 0))
+        extras = result.setdefault("extras", {})
+        useful = sum(l for l in range(50, 128) for _ in range(10))
+        c3 = {"metric": "backbones/sec (lengths 50..127 x 10, T=1000, batch_size 512) through sampling.sample, final_only",
+              "backbones": 780, "useful_tokens": useful, "padded_tokens": 512 * 101 + 268 * 127}
+        for mode in ("philox", "torch"):
+            sampling.NOISE_MODE = mode
+            torch.manual_seed(7344)
+            if mode == "philox":  # first call of these (B, L): workspaces + graph capture, not timed
+                sampling.sample(model, ds, n=1, sweep_lengths=(100, 102), batch_size=512, final_only=True)
+                sampling.sample(model, ds, n=10, sweep_lengths=(50, 128), batch_size=512, final_only=True)
+                torch.manual_seed(7344)
+            t3 = time.perf_counter()
+            res3 = sampling.sample(model, ds, n=10, sweep_lengths=(50, 128), batch_size=512, final_only=True)
+            dt3 = time.perf_counter() - t3
+            assert len(res3) == 780 and all(np.isfinite(r).all() for r in res3)
+            c3[mode] = {"value": 780 / dt3, "unit": "backbones/s", "seconds": dt3, "passes": 1,
+                        "useful_tokens_per_s": useful / dt3}
+        extras["c3"] = c3
+        he = {"metric": f"backbones/sec (L={L}, T={T}, bs={B}) through p_sample_loop: host x_init in, final angles out (fd_sample_ex)"}
+        x_host = x_init.cpu()
+        for mode in ("philox", "torch"):
+            sampling.NOISE_MODE = mode
+            torch.manual_seed(7344)
+            th = time.perf_counter()
+            fin = sampling.p_sample_loop(model, [L] * B, x_host, T, betas, is_angle=[True] * 6, final_only=True)
+            dth = time.perf_counter() - th
+            assert tuple(fin.shape) == (1, B, L, 6) and torch.isfinite(fin).all()
+            he[mode] = {"value": B / dth, "unit": "backbones/s", "seconds": dth, "passes": 1}
+        sampling.NOISE_MODE = "philox"
+        extras["host_entry"] = he
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(B, L, T, shape)
     print(json.dumps(result), flush=True)

@@ -135,6 +135,8 @@ struct fd_model {
   std::vector<Workspace> cache;
   uint64_t use_clock = 0;
   Workspace ws;      // the current one (moved in and out of `cache`)
+  UpdateDyn dyn_host{};  // per-run values of the sampling loop in progress (fd_sample_begin_dev .. fd_sample_end_dev)
+  int run_t = -1;        // next timestep of that run (-1: none left)
   // profiling
   int profile_every = 0;
   double prof_ms[KC_COUNT] = {0};
@@ -1165,9 +1167,8 @@ int fd_p_sample_step(fd_model* m, const float* x, int t, const int32_t* lens, in
   return check_flag(m);
 }
 
-int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
-                  const void* noise_dev, uint64_t seed, int64_t seq_offset, void* out_dev, int full_history,
-                  void* hip_stream) {
+int fd_sample_begin_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
+                        uint64_t seed, int64_t seq_offset, void* out_dev, int full_history, void* hip_stream) {
   if (int rc = check_shape(m, B, L, t_start)) return rc;
   if (!x_init_dev || !lens_dev || !out_dev) return fail(FD_E_INVALID, "null argument");
   if (full_history < 0) return fail(FD_E_INVALID, "full_history = %d", full_history);
@@ -1178,6 +1179,8 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
   const size_t n = (size_t)B * L * m->cfg.n_features;
   HIP_TRY(hipMemcpyAsync(w.x, x_init_dev, n * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(w.lens, lens_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  if (m->varlen && full_history)  // packed rows: positions beyond a sequence's length are never written
+    HIP_TRY(hipMemsetAsync(out_dev, 0, ((size_t)(t_start + full_history) / full_history) * n * 4, s));
   if (int rc = prepare_rows(m, s, m->varlen)) return rc;
   if (m->use_graph && !(w.graph && w.graph_fuse_ln == m->fuse_ln)) {
     // first use of this (B, L): the warm-up step and the capture run on the model's stream and need the
@@ -1186,19 +1189,34 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
     if (int rc = ensure_graph(m)) return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
   }
-  UpdateDyn dyn;
+  UpdateDyn& dyn = m->dyn_host;
   memset(&dyn, 0, sizeof dyn);
-  dyn.noise = static_cast<const float*>(noise_dev);
   dyn.hist = full_history ? static_cast<float*>(out_dev) : nullptr;
   dyn.seed = seed;
   dyn.seq_offset = seq_offset;
   dyn.t_start = t_start;
   dyn.hist_every = full_history;
-  hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, s, w.dyn, dyn);
+  m->run_t = t_start;
   if (int rc = set_t(m, s, t_start)) return rc;
-  const int nsteps = t_start + 1;
-  for (int i = 0; i < nsteps; ++i) {
-    const bool prof = m->profile_every > 0 && (i % m->profile_every) == m->profile_every / 2;
+  return FD_OK;
+}
+
+int fd_sample_steps_dev(fd_model* m, int n_steps, const void* noise_dev, int noise_t0, void* hip_stream) {
+  if (!m || !m->finalized || m->ws.B == 0) return fail(FD_E_STATE, "fd_sample_steps_dev without fd_sample_begin_dev");
+  if (n_steps < 0 || n_steps > m->run_t + 1) return fail(FD_E_INVALID, "n_steps = %d with %d steps left", n_steps, m->run_t + 1);
+  if (noise_dev && (noise_t0 < 0 || noise_t0 > m->run_t - n_steps + 1))  // (the row of t = 0 is read too, and multiplied by sigma_0 = 0)
+    return fail(FD_E_INVALID, "noise rows start at t = %d, the steps run down to t = %d", noise_t0, m->run_t - n_steps + 1);
+  HIP_TRY(hipSetDevice(m->device));
+  Workspace& w = m->ws;
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  // the kernel reads the draw of step t at noise + t * (B L F): rebase the chunk (row 0 = step noise_t0)
+  const size_t n = (size_t)w.B * w.L * m->cfg.n_features;
+  UpdateDyn dyn = m->dyn_host;
+  dyn.noise = noise_dev ? static_cast<const float*>(noise_dev) - (ptrdiff_t)noise_t0 * (ptrdiff_t)n : nullptr;
+  hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, s, w.dyn, dyn);
+  for (int i = 0; i < n_steps; ++i) {
+    const int done = m->dyn_host.t_start - m->run_t;  // steps already run
+    const bool prof = m->profile_every > 0 && (done % m->profile_every) == m->profile_every / 2;
     if (m->use_graph && !prof) {
       HIP_TRY(hipGraphLaunch(w.graph, s));
     } else {
@@ -1208,9 +1226,28 @@ int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int
       mode.profile = prof;
       if (int rc = run_step(m, s, mode)) return rc;
     }
+    --m->run_t;
   }
-  if (!full_history) HIP_TRY(hipMemcpyAsync(out_dev, w.x, n * 4, hipMemcpyDeviceToDevice, s));
   return FD_OK;
+}
+
+int fd_sample_end_dev(fd_model* m, void* out_dev, void* hip_stream) {
+  if (!m || !m->finalized || m->ws.B == 0) return fail(FD_E_STATE, "fd_sample_end_dev without fd_sample_begin_dev");
+  if (m->run_t >= 0) return fail(FD_E_STATE, "%d reverse steps have not been run", m->run_t + 1);
+  Workspace& w = m->ws;
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  const size_t n = (size_t)w.B * w.L * m->cfg.n_features;
+  if (!m->dyn_host.hist_every) HIP_TRY(hipMemcpyAsync(out_dev, w.x, n * 4, hipMemcpyDeviceToDevice, s));
+  return FD_OK;
+}
+
+int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
+                  const void* noise_dev, uint64_t seed, int64_t seq_offset, void* out_dev, int full_history,
+                  void* hip_stream) {
+  if (int rc = fd_sample_begin_dev(m, x_init_dev, lens_dev, B, L, t_start, seed, seq_offset, out_dev, full_history, hip_stream))
+    return rc;
+  if (int rc = fd_sample_steps_dev(m, t_start + 1, noise_dev, 0, hip_stream)) return rc;
+  return fd_sample_end_dev(m, out_dev, hip_stream);
 }
 
 int fd_sample(fd_model* m, const float* x_init, const int32_t* lens, int B, int L, int t_start, const float* noise,

@@ -63,9 +63,13 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 
 __device__ __forceinline__ void swap32(unsigned& vdst, unsigned& src) {
   // lanes 32-63 of vdst <-> lanes 0-31 of src (v_permlane32_swap_b32)
+#ifdef FDMI_NOSWAP  // ablation build (wrong results): what do the half-wave exchanges cost?
+  asm volatile("" : "+v"(vdst), "+v"(src));
+#else
   const auto r = __builtin_amdgcn_permlane32_swap(vdst, src, false, false);
   vdst = r[0];
   src = r[1];
+#endif
 }
 
 // byte offset of 16-byte unit u (0-3 hi, 4-7 lo) of column block cb of token row `row`; nb = blocks per row

@@ -384,7 +384,12 @@ class BertForDiffusionBase:
         return self
 
     def set_option(self, name: str, value: int):
+        """fd_set_option; returns the value the option had before (0 if it was never set through this object)."""
         _binding.check(_binding.load().fd_set_option(self._ensure_handle(), name.encode(), int(value)))
+        opts = self.__dict__.setdefault("_fd_options", {})
+        prev = opts.get(name, 0)
+        opts[name] = int(value)
+        return prev
 
     # ------------------------------------------------------------------ forward
     @staticmethod

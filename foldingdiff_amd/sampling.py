@@ -8,8 +8,12 @@ with the schedule tables and the step counter resident on the device.
 
 Per-step noise (the reference's ``torch.randn_like(x)``, sampling.py:73):
   * ``NOISE_MODE = "torch"`` (default): the draws are taken from torch's global
-    CPU generator in the reference's order and uploaded, so after
-    ``torch.manual_seed(s)`` the sampled angles match the reference CPU path.
+    CPU generator in the reference's order, so after ``torch.manual_seed(s)`` the
+    sampled angles match the reference CPU path.  They are STREAMED: a host thread
+    draws ``NOISE_CHUNK`` steps at a time into pinned buffers, a copy stream uploads
+    a chunk while the device consumes the previous one (``_StepNoise``,
+    ``_run_fd_sample_streamed``) -- the [T, B, L, F] array (1.57 GB at batch 512,
+    length 128) is never materialised and the first launch does not wait for it.
   * ``NOISE_MODE = "philox"`` (or env ``FOLDINGDIFF_AMD_NOISE=philox``): noise is
     generated inside the update kernel (Philox4x32-10); a 64-bit seed is drawn
     from torch's CPU generator, so ``torch.manual_seed`` still makes runs
@@ -29,6 +33,8 @@ from . import datasets as dsets
 from . import modelling
 
 NOISE_MODE = os.environ.get("FOLDINGDIFF_AMD_NOISE", "torch")
+NOISE_CHUNK = int(os.environ.get("FOLDINGDIFF_AMD_NOISE_CHUNK", "32"))   # reverse steps per uploaded chunk
+STREAM_NOISE = os.environ.get("FOLDINGDIFF_AMD_STREAM_NOISE", "1") != "0"
 
 
 def _as_f32(t: torch.Tensor) -> np.ndarray:
@@ -90,6 +96,107 @@ def _run_fd_sample(h, x0: np.ndarray, lens: np.ndarray, t_start: int, zs: Option
         out.ctypes.data_as(C.c_void_p), full_history))
 
 
+class _StepNoise:
+    """The reference's per-step draws for reverse steps t = t_start .. 1, produced in the reference's order (one
+    ``torch.randn`` of the WHOLE batch shape per step, from torch's global CPU generator) but handed out chunk by
+    chunk.  ``rows=(lo, hi)``: keep only that slice of the batch (a rank's shard; the other rows are drawn -- the
+    stream must advance exactly as in a single-process run -- and dropped at once, so memory stays bounded)."""
+
+    def __init__(self, t_start: int, shape, rows: Optional[Tuple[int, int]] = None):
+        self.t_start, self.shape = t_start, tuple(shape)
+        self.rows = rows if rows is not None else (0, self.shape[0])
+        self.local_shape = (self.rows[1] - self.rows[0],) + self.shape[1:]
+
+    def chunks(self, n: int):
+        """(t_lo, t_hi) of the chunks, first chunk first: steps run from t_start down to 0; a chunk holds the rows
+        t_lo .. t_hi (row i = step t_lo + i).  The step t = 0 draws nothing: its row is zero."""
+        t_hi = self.t_start
+        while t_hi >= 0:
+            t_lo = max(t_hi - n + 1, 0)
+            yield t_lo, t_hi
+            t_hi = t_lo - 1
+
+    def fill(self, t_lo: int, t_hi: int, dst: torch.Tensor) -> None:
+        """Draw the steps t_hi .. max(t_lo, 1) (in that order) into dst[t - t_lo]; dst: [>= t_hi - t_lo + 1, b, L, F]."""
+        lo, hi = self.rows
+        whole = (lo, hi) == (0, self.shape[0])
+        for t in range(t_hi, t_lo - 1, -1):
+            if t == 0:
+                dst[0].zero_()
+            elif whole:
+                torch.randn(self.shape, dtype=torch.float32, out=dst[t - t_lo])
+            else:
+                dst[t - t_lo].copy_(torch.randn(self.shape, dtype=torch.float32)[lo:hi])
+
+    def materialize(self) -> np.ndarray:
+        """All rows at once, [t_start + 1, b, L, F] (row 0 zero): the array fd_sample_ex takes."""
+        out = torch.zeros((self.t_start + 1,) + self.local_shape, dtype=torch.float32)
+        self.fill(0, self.t_start, out)
+        return out.numpy()
+
+
+def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start: int, noise: _StepNoise, seq_offset: int,
+                            out: np.ndarray, full_history: int) -> None:
+    """Reverse steps t_start .. 0 with the step noise streamed to the device (fd_sample_begin_dev / _steps_dev /
+    _end_dev): chunk k + 1 is drawn by a host thread and uploaded on a copy stream while the device runs chunk k."""
+    import threading
+    dev = model.device
+    lib = _binding.load()
+    B, L, F = x0.shape
+    nrow = min(NOISE_CHUNK, t_start + 1)
+    pinned = [torch.empty((nrow, B, L, F), dtype=torch.float32).pin_memory() for _ in range(2)]
+    dbuf = [torch.empty((nrow, B, L, F), dtype=torch.float32, device=dev) for _ in range(2)]
+    copy_s, run_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [None, None]
+    x_d = torch.from_numpy(x0).to(dev)
+    lens_d = torch.from_numpy(lens).to(dev)
+    rows = out.shape[0]
+    out_d = torch.empty((rows, B, L, F), dtype=torch.float32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    chunks = list(noise.chunks(nrow))
+    err: List[BaseException] = []
+
+    def draw(k):
+        try:
+            noise.fill(chunks[k][0], chunks[k][1], pinned[k % 2])
+        except BaseException as e:  # surfaced by the main thread
+            err.append(e)
+
+    th = threading.Thread(target=draw, args=(0,))
+    th.start()
+    _binding.check(lib.fd_sample_begin_dev(h, C.c_void_p(x_d.data_ptr()), C.c_void_p(lens_d.data_ptr()), B, L, t_start,
+                                           C.c_uint64(0), C.c_int64(seq_offset), C.c_void_p(out_d.data_ptr()), full_history,
+                                           C.c_void_p(run_s.cuda_stream)))
+    for k, (t_lo, t_hi) in enumerate(chunks):
+        th.join()
+        if err:
+            raise err[0]
+        b = k % 2
+        with torch.cuda.stream(copy_s):
+            if consumed[b] is not None:
+                copy_s.wait_event(consumed[b])          # the device is done with this buffer's previous content
+            dbuf[b][: t_hi - t_lo + 1].copy_(pinned[b][: t_hi - t_lo + 1], non_blocking=True)
+            copied[b].record(copy_s)
+        if k + 1 < len(chunks):
+            if k >= 1:
+                copied[(k + 1) % 2].synchronize()       # its upload has left the pinned buffer the thread writes next
+            th = threading.Thread(target=draw, args=(k + 1,))
+            th.start()
+        run_s.wait_event(copied[b])
+        _binding.check(lib.fd_sample_steps_dev(h, t_hi - t_lo + 1, C.c_void_p(dbuf[b].data_ptr()), t_lo,
+                                               C.c_void_p(run_s.cuda_stream)))
+        consumed[b] = torch.cuda.Event()
+        consumed[b].record(run_s)
+    _binding.check(lib.fd_sample_end_dev(h, C.c_void_p(out_d.data_ptr()), C.c_void_p(run_s.cuda_stream)))
+    run_s.synchronize()
+    _binding.check(lib.fd_check_finite(h))
+    out[:] = out_d.cpu().numpy()
+
+
+_run_fd_sample_default = _run_fd_sample
+
+
 @torch.no_grad()
 def p_sample_loop(
     model,
@@ -104,6 +211,7 @@ def p_sample_loop(
     step_noise: Optional[np.ndarray] = None,
     seed: Optional[int] = None,
     seq_offset: int = 0,
+    draw_batch: Optional[Tuple[int, int, int]] = None,
 ) -> torch.Tensor:
     """Run the whole reverse process from ``noise``.  Returns a CPU tensor of shape
     (timesteps, batch_size, seq_len, n_ft) -- entry j is the state after step
@@ -129,7 +237,18 @@ def p_sample_loop(
     elif seed is not None:
         zs = None
     elif NOISE_MODE == "torch":
-        zs, seed = _draw_step_noise(timesteps, (B, L, F)), 0
+        # the reference's draws, streamed; ``draw_batch = (B_all, lo, hi)``: this call is rows lo..hi of a larger batch
+        # whose draws have the shape (B_all, L, F) (multi-rank sample())
+        b_all, lo, hi = draw_batch if draw_batch is not None else (B, 0, B)
+        assert hi - lo == B
+        stream = _StepNoise(timesteps - 1, (b_all, L, F), (lo, hi))
+        rows = 1 if final_only else -(-timesteps // history_every)
+        out = np.empty((rows, B, L, F), dtype=np.float32)
+        if STREAM_NOISE and _run_fd_sample is _run_fd_sample_default and getattr(getattr(model, "device", None), "type", "") == "cuda":
+            _run_fd_sample_streamed(model, h, x0, lens, timesteps - 1, stream, seq_offset, out, 0 if final_only else history_every)
+        else:
+            _run_fd_sample(h, x0, lens, timesteps - 1, stream.materialize(), 0, seq_offset, out, 0 if final_only else history_every)
+        return torch.from_numpy(out)
     elif NOISE_MODE == "philox":
         zs, seed = None, _draw_philox_seed()
     else:
@@ -250,27 +369,33 @@ def sample(
         if trim_to_length:
             noise = noise[:, : max(these), :]
         B, L, F = noise.shape
-        # per-step noise of the WHOLE batch in the reference's draw order: identical on every rank, sliced below
+        # per-step noise: the reference's draws of the WHOLE batch (identical on every rank; each rank keeps its rows as
+        # they are drawn, p_sample_loop(draw_batch=...)), or one Philox seed for the batch
         if NOISE_MODE == "torch":
-            zs, seed = _draw_step_noise(T, (B, L, F)), None
+            seed = None
+            if world > 1 and start == 0:
+                logging.info("torch-order step noise under torch.distributed: every rank draws the whole batch's stream "
+                             "(serial host RNG); FOLDINGDIFF_AMD_NOISE=philox scales with the number of GPUs")
         elif NOISE_MODE == "philox":
-            zs, seed = None, _draw_philox_seed()
+            seed = _draw_philox_seed()
         else:
             raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
         bounds = fdist.shard_by_tokens(these, world) if world > 1 else [(0, B)]
         lo, hi = bounds[rank]
         rows = 1 if final_only else -(-T // history_every)
         if hi > lo:
-            model.set_option("varlen", 1)
+            prev_varlen = model.set_option("varlen", 1)
             try:
                 traj = p_sample_loop(
                     model=model, lengths=these[lo:hi], noise=noise[lo:hi], timesteps=T,
                     betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
                     disable_pbar=disable_pbar, final_only=final_only, history_every=history_every,
-                    step_noise=None if zs is None else zs[:, lo:hi], seed=seed, seq_offset=lo)
+                    seed=seed, seq_offset=lo, draw_batch=(B, lo, hi))
             finally:
-                model.set_option("varlen", 0)
+                model.set_option("varlen", prev_varlen if prev_varlen is not None else 0)
         else:
+            if NOISE_MODE == "torch":  # an empty shard still advances the generator exactly as the other ranks do
+                _StepNoise(T - 1, (B, L, F), (0, 0)).materialize()
             traj = torch.zeros((rows, 0, L, F), dtype=torch.float32)
         if world > 1:  # the single exchange of the path: [b_r, rows, L, F] blocks -> every rank holds the whole batch
             device = getattr(model, "device", torch.device("cpu"))

@@ -115,7 +115,8 @@ void fd_destroy(fd_model* m);
  *                0: eager launches.
  *   "varlen"     fd_sample / fd_sample_dev with FD_PREC_F16X3: 1 = positions >= lens[b] are not computed at all
  *                (the reference computes them and sampling.sample cuts them away, sampling.py:56-58, :201-203);
- *                positions < lens[b] are bit-identical either way.  Padded positions of `out` then keep x_init.
+ *                positions < lens[b] are bit-identical either way.  Padded positions of the final `out` then keep x_init;
+ *                padded positions of history rows are zero.
  *                0 (default): every position evolves as in the reference's p_sample_loop.
  *   "split_qkv"  FD_PREC_F16X3: 1 = project q | k and v^T in two launches even when n_heads % 6 == 0 would allow one
  *                (A/B measurements, tests); 0 (default).
@@ -167,6 +168,21 @@ int fd_sample_ex(fd_model* m, const float* x_init, const int32_t* lens, int B, i
 int fd_sample_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
                   const void* noise_dev, uint64_t seed, int64_t seq_offset, void* out_dev, int full_history,
                   void* hip_stream);
+
+/* The same loop in pieces, for callers that stream the per-step noise instead of materialising [T][B][L][F]
+ * (sampling.py draws the reference's torch.randn_like sequence chunk by chunk on a host thread and uploads it on a copy
+ * stream while the previous chunk is consumed):
+ *   fd_sample_begin_dev   everything fd_sample_dev does before its first step (uploads x_init / lens into the workspace,
+ *                         row table, graph); `out_dev` receives the history rows as in fd_sample_dev
+ *   fd_sample_steps_dev   the next n_steps reverse steps, enqueued on the stream; noise_dev = [rows][B][L][F] device
+ *                         buffer whose row i is the draw of step t = noise_t0 + i (it must cover every step of the call,
+ *                         t = 0 included -- that row is read and multiplied by sigma_0 = 0), or NULL (Philox)
+ *   fd_sample_end_dev     after the last step: copies the final state to out_dev when full_history == 0
+ * fd_sample_dev(...) == begin; steps(t_start + 1, noise, 0); end.  Stream-ordered like fd_sample_dev. */
+int fd_sample_begin_dev(fd_model* m, const void* x_init_dev, const void* lens_dev, int B, int L, int t_start,
+                        uint64_t seed, int64_t seq_offset, void* out_dev, int full_history, void* hip_stream);
+int fd_sample_steps_dev(fd_model* m, int n_steps, const void* noise_dev, int noise_t0, void* hip_stream);
+int fd_sample_end_dev(fd_model* m, void* out_dev, void* hip_stream);
 
 /* Fill out_dev[n] (device, float32) with the Philox N(0,1) stream used for step
  * t of a [B][L][F] batch -- exposes the perf-mode generator for tests. */

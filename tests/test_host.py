@@ -160,6 +160,37 @@ def test_step_noise_draw_order_matches_reference():
     assert np.array_equal(z, g["step_noise"])
 
 
+def test_streamed_step_noise_is_the_reference_draw_order():
+    """_StepNoise (the chunked producer behind the default sampling path) hands out exactly the draws of
+    _draw_step_noise -- whole batch, a rank's row slice, any chunking -- and leaves the generator where a
+    single-process run leaves it."""
+    shape = (5, 7, 6)
+    torch.manual_seed(31)
+    want = sampling._draw_step_noise(9, shape)
+    after = torch.rand(1).item()
+    torch.manual_seed(31)
+    assert np.array_equal(sampling._StepNoise(8, shape).materialize(), want)
+    assert torch.rand(1).item() == after
+    torch.manual_seed(31)
+    assert np.array_equal(sampling._StepNoise(8, shape, (2, 4)).materialize(), want[:, 2:4])
+    assert torch.rand(1).item() == after                      # a shard consumes the whole batch's stream
+    torch.manual_seed(31)
+    assert sampling._StepNoise(8, shape, (3, 3)).materialize().shape == (9, 0, 7, 6)
+    assert torch.rand(1).item() == after                      # and so does an empty shard
+    for n in (1, 2, 4, 9, 32):
+        torch.manual_seed(31)
+        st = sampling._StepNoise(8, shape)
+        got = np.full((9,) + shape, np.nan, np.float32)
+        seen = []
+        for lo, hi in st.chunks(n):
+            buf = torch.empty((min(n, 9),) + shape)
+            st.fill(lo, hi, buf)
+            got[lo:hi + 1] = buf[: hi - lo + 1].numpy()
+            seen.append((lo, hi))
+        assert seen[0][1] == 8 and seen[-1][0] == 0 and all(a[0] == b[1] + 1 for a, b in zip(seen, seen[1:]))
+        assert np.array_equal(got, want), n
+
+
 def test_gelu_rational_erf_accuracy():
     """The fp16x3 GEMM epilogue evaluates erf as a rational function (csrc/img_common.h:erf_rational,
     coefficients restated here): it must stay in libm-erff's error class against float64 erf, and the
