@@ -503,7 +503,8 @@ int run_step(fd_model* m, hipStream_t s, const StepMode& mode) {
     const LayerDev& lw = m->layers[li];
     PROF(KC_GEMM_QKV, gemm(m, EPI_BIAS, w.h, lw.wqkv, lw.bqkv, nullptr, w.qkv, M, 3 * d, d, s));
     bool ok = true;
-    PROF(KC_ATTN, ok = launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s));
+    PROF(KC_ATTN, ok = launch_attention_f32(w.qkv, lw.demb, w.lens, w.ctx, B, L, c.n_heads, c.max_pos, s,
+                                            c.pos_type == FD_POS_RELATIVE_KEY_QUERY));
     if (!ok) return fail(FD_E_UNSUPPORTED, "attention: sequence length %d not supported by the fp32 kernel (max 128)", L);
     bool fused = false;
     if (fuse_ln)
@@ -649,6 +650,8 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       a.B = B; a.H = H; a.LTOT = w.LTOT; a.NKT = w.NKT; a.maxpos = c.max_pos;
       a.q_scale = lw.s_q; a.k_scale = lw.s_k; a.v_scale = lw.s_v; a.ctx_scale = lw.s_v;
       a.r_scale = lw.demb_s.p ? lw.s_k / lw.demb_s.scale : 1.f;
+      a.r_scale_k = lw.demb_s.p ? lw.s_q / lw.demb_s.scale : 1.f;
+      a.rkq = c.pos_type == FD_POS_RELATIVE_KEY_QUERY;
       a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 : nullptr;
       bool ok = true;
       PROF(KC_ATTN, ok = launch_attention_img(a, L, s));
@@ -923,9 +926,8 @@ int fd_create(const fd_config* cfg, int device_id, fd_model** out) {
   if (c.d_model > 1024) return fail(FD_E_UNSUPPORTED, "d_model=%d > 1024", c.d_model);
   if (c.d_ff < 32 || c.d_ff % 32) return fail(FD_E_UNSUPPORTED, "d_ff=%d must be a positive multiple of 32", c.d_ff);
   if (c.n_layers < 1 || c.max_pos < 1) return fail(FD_E_INVALID, "n_layers=%d max_pos=%d", c.n_layers, c.max_pos);
-  if (c.pos_type == FD_POS_RELATIVE_KEY_QUERY)
-    return fail(FD_E_UNSUPPORTED, "position_embedding_type=relative_key_query is not implemented");
-  if (c.pos_type != FD_POS_ABSOLUTE && c.pos_type != FD_POS_RELATIVE_KEY) return fail(FD_E_INVALID, "pos_type=%d", c.pos_type);
+  if (c.pos_type != FD_POS_ABSOLUTE && c.pos_type != FD_POS_RELATIVE_KEY && c.pos_type != FD_POS_RELATIVE_KEY_QUERY)
+    return fail(FD_E_INVALID, "pos_type=%d", c.pos_type);
   if (c.decoder != FD_DEC_MLP && c.decoder != FD_DEC_LINEAR) return fail(FD_E_INVALID, "decoder=%d", c.decoder);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1030,7 +1032,7 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
       lw.s_v = scale_for(dense_bound(wqkv.data(), bqkv.data(), 2 * (int)d, 3 * (int)d, (int)d, hb.l2));  // also bounds ctx
     }
     lw.demb = nullptr;
-    if (c.pos_type == FD_POS_RELATIVE_KEY) {
+    if (c.pos_type != FD_POS_ABSOLUTE) {  // relative_key and relative_key_query
       NEED(de, p + "attention.self.distance_embedding.weight");
       UP(lw.demb, de);
       if (precision == FD_PREC_F16X3)

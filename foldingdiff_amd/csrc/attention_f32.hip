@@ -40,7 +40,8 @@ __device__ __forceinline__ float exp_neg(float x) {
   return fmaf(e, err * 0.693147180559945f, e);
 }
 
-template <int T, bool REL>
+// RKQ: relative_key_query -- the score also gets k_r . E[l - r + maxpos - 1] (HF BertSelfAttention 4.11.3; bin/train.py:305-307)
+template <int T, bool REL, bool RKQ = false>
 __global__ __launch_bounds__(256 * HPB) void attn_f32_kernel(const float* __restrict__ qkv,
                                                              const float* __restrict__ demb,
                                                              const int* __restrict__ lens, float* __restrict__ ctx,
@@ -147,6 +148,42 @@ __global__ __launch_bounds__(256 * HPB) void attn_f32_kernel(const float* __rest
         }
       }
     }
+    if constexpr (RKQ) {
+      // key term: tile K_t E_q^T (rows = keys rowmap(r, half), columns = band index, lane l31) for the band tiles q = T-1-t
+      // and q+1 of S tile t; element (query li, key rj = this lane) needs row rj, column (li - rj + 31) & 31 of the lower
+      // tile (li <= rj) or the upper one: a transposing gather through the wave's [32][36] scratch
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const int q = T - 1 - t + side;
+          f32x16 kacc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) kacc[r] = 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(&Kh[(32 * t + l31) * KLD + 8 * g + 4 * half]);
+            const f32x4 eb = *reinterpret_cast<const f32x4*>(&Es[(l0 + 32 * q + l31) * KLD + 8 * g + 4 * half]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], eb[s], kacc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2) + 4 * half) * KLD + l31] = kacc[r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int li = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int delta = li - l31 + 31;   // band column of the tile pair for (query li, key l31)
+            const float v = Pw[l31 * KLD + (delta & 31)];
+            if ((delta >= 32) == (side == 1)) sacc[t][r] += v;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
     // scale, mask, softmax over r (row li lives in this lane's 32-lane half)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(256 * HPB) void attn_f32_kernel(const float* __rest
   }
 }
 
-template <int T, bool REL>
+template <int T, bool REL, bool RKQ = false>
 static void launch_t(const float* qkv, const float* demb, const int* lens, float* ctx, int B, int L, int H, int maxpos,
                      hipStream_t s) {
   constexpr int LP = 32 * T;
@@ -216,23 +253,24 @@ static void launch_t(const float* qkv, const float* demb, const int* lens, float
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<T, REL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<T, REL, RKQ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int hgroups = (H + HPB - 1) / HPB;
-  hipLaunchKernelGGL((attn_f32_kernel<T, REL>), dim3(B * hgroups), dim3(256 * HPB), smem, s, qkv, demb, lens, ctx, L, H,
+  hipLaunchKernelGGL((attn_f32_kernel<T, REL, RKQ>), dim3(B * hgroups), dim3(256 * HPB), smem, s, qkv, demb, lens, ctx, L, H,
                      maxpos);
 }
 
 bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
-                          int maxpos, hipStream_t s) {
+                          int maxpos, hipStream_t s, int rkq) {
   if (L < 1 || L > 128) return false;
   const int T = (L + 31) / 32;
   const bool rel = dist_emb != nullptr;
 #define FD_ATTN_CASE(TT)                                                          \
   case TT:                                                                        \
-    if (rel) launch_t<TT, true>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);    \
+    if (rel && rkq) launch_t<TT, true, true>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s); \
+    else if (rel) launch_t<TT, true>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s); \
     else launch_t<TT, false>(qkv, dist_emb, lens, ctx, B, L, H, maxpos, s);       \
     break;
   switch (T) {

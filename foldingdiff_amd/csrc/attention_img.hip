@@ -57,8 +57,14 @@ struct Geo {
 // (loads retire in order: a table fetch from L2 behind a V copy used to stall the band phase until V had landed).
 // Q comes straight from global memory into registers, one item ahead.
 // SAFE: every wait is vmcnt(0) (debug aid for the counted-wait bookkeeping)
-template <int T, bool REL, bool ELDS, int NG, bool SAFE, bool PROF = false>
+// RKQ: position_embedding_type = "relative_key_query" (HF BertSelfAttention 4.11.3; offered by the reference's training CLI,
+// bin/train.py:305-307): the score also gets  k_r . E[l - r + maxpos - 1]  -- the same band of the distance table paired with
+// the KEYS.  Per S^T tile t that is two more dense 32 x 32 tiles K_t E^T (rows = keys, i.e. the S^T tile's own rows) against the
+// band tiles T-1-t and T-t, skewed through the same per-wave scratch: lane (query l31) register r (key kl) reads
+// scratch[r][half][(l31 - kl + 31) & 31] -- the scratch ROW is the register's own, only the column is skewed.
+template <int T, bool REL, bool ELDS, int NG, bool SAFE, bool PROF = false, bool RKQ = false>
 __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
+  static_assert(REL || !RKQ, "relative_key_query is a relative position type");
   using G = Geo<T, ELDS>;
   constexpr int LP = G::LP;
   constexpr int GSZ = REL ? G::G_REL : G::G_ABS;
@@ -316,6 +322,44 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next band tile overwrites this scratch
           __builtin_amdgcn_wave_barrier();
+          if constexpr (RKQ) {
+            // the key term against the SAME band tile: S^T tile T-1-qq takes it as its lower tile, S^T tile T-qq as its upper one
+            const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
+            const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
+            const float rk = p.r_scale_k / p.r_scale;  // band weights carry r_scale (k_scale / table scale); this term needs q_scale / table scale
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              const int t = side == 0 ? T - 1 - qq : T - qq;
+              if (t < 0 || t >= T) continue;
+              const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
+              const int ksz = (l31 >> 3) & 1;
+              const f16x8 kh0 = *reinterpret_cast<const f16x8*>(pc + (((0 + half) ^ ksz) << 7));
+              const f16x8 kl0 = *reinterpret_cast<const f16x8*>(pc + (((4 + half) ^ ksz) << 7));
+              const f16x8 kh1 = *reinterpret_cast<const f16x8*>(pc + (((2 + half) ^ ksz) << 7));
+              const f16x8 kl1 = *reinterpret_cast<const f16x8*>(pc + (((6 + half) ^ ksz) << 7));
+              f32x16 kacc;
+              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, eh0, zero16, 0, 0, 0);
+              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, el0, kacc, 0, 0, 0);
+              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, eh0, kacc, 0, 0, 0);
+              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, eh1, kacc, 0, 0, 0);
+              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, el1, kacc, 0, 0, 0);
+              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, eh1, kacc, 0, 0, 0);
+              // scratch [register r][lane]: row (key) 8q + 4 half + e of column l31 at r * 256 + lane * 4 (as above, plain stores)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Rw[r * 64 + lane] = kacc[r];
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float g = Rw[r * 64 + half * 32 + ((l31 - kl + 31) & 31)] * rk;
+                sacc[t][r] = __builtin_fmaf(g, side == 0 ? bw_lo[r] : bw_hi[r], sacc[t][r]);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
         }
       }
     }
@@ -440,10 +484,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
-// NG = groups (item streams) per workgroup = 2: one 8-wave workgroup per CU, both groups behind the same barriers, one
-// copy of the distance table.  (NG = 1 -- independent 4-wave workgroups with a table copy each, exactly 80 KiB -- was
-// measured at 179 vs 131 us: two such workgroups do not become co-resident, profiles/r02_attention_notes.log.)
-template <int T, bool REL, bool ELDS, int NG>
+template <int T, bool REL, bool ELDS, int NG, bool RKQ>
 static void launch_ng(const AttnImgArgs& p, hipStream_t s) {
   using G = Geo<T, ELDS>;
   constexpr int smem = G::E_BYTES + NG * (REL ? G::G_REL : G::G_ABS);
@@ -454,11 +495,11 @@ static void launch_ng(const AttnImgArgs& p, hipStream_t s) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, false, false, RKQ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, true, false, RKQ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_img_kernel<T, REL, ELDS, NG, false, true, RKQ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipDeviceProp_t prop;
     n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -467,14 +508,23 @@ static void launch_ng(const AttnImgArgs& p, hipStream_t s) {
   const int nitems = p.B * p.H * p.NKT;
   int grid = n_cu[dev] * (NG == 1 ? 2 : 1);  // 8 waves per CU either way
   if (grid > (nitems + NG - 1) / NG) grid = (nitems + NG - 1) / NG;
-  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, false, true>), dim3(grid), dim3(256 * NG), smem, s, p);
-  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, true>), dim3(grid), dim3(256 * NG), smem, s, p);
-  else hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, false>), dim3(grid), dim3(256 * NG), smem, s, p);
+  if (p.stamps) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, false, true, RKQ>), dim3(grid), dim3(256 * NG), smem, s, p);
+  else if (safe) hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, true, false, RKQ>), dim3(grid), dim3(256 * NG), smem, s, p);
+  else hipLaunchKernelGGL((attn_img_kernel<T, REL, ELDS, NG, false, false, RKQ>), dim3(grid), dim3(256 * NG), smem, s, p);
 }
 
+// NG = groups (item streams) per workgroup = 2: one 8-wave workgroup per CU, both groups behind the same barriers, one
+// copy of the distance table.  (NG = 1 -- independent 4-wave workgroups with a table copy each, exactly 80 KiB -- was
+// measured at 179 vs 131 us: two such workgroups do not become co-resident, profiles/r02_attention_notes.log.)
 template <int T, bool REL, bool ELDS>
 static void launch(const AttnImgArgs& p, hipStream_t s) {
-  launch_ng<T, REL, ELDS, 2>(p, s);
+  if constexpr (REL) {
+    if (p.rkq) {
+      launch_ng<T, REL, ELDS, 2, true>(p, s);
+      return;
+    }
+  }
+  launch_ng<T, REL, ELDS, 2, false>(p, s);
 }
 
 }  // namespace ai

@@ -39,8 +39,9 @@ void launch_embed(const float* x, const float* w_in, const float* b_in, const fl
 // relative_key score term.  qkv: [B*L, 3d] (q | k | v), ctx: [B*L, d].
 // dist_emb: [2*maxpos-1, 32] of this layer, or null for absolute positions.
 // Returns false when L is beyond what this build tiles (L > 128).
+// rkq != 0: relative_key_query (the key term k_r . E[l - r + maxpos - 1] as well)
 bool launch_attention_f32(const float* qkv, const float* dist_emb, const int* lens, float* ctx, int B, int L, int H,
-                          int maxpos, hipStream_t s);
+                          int maxpos, hipStream_t s, int rkq = 0);
 
 // K8 tail + K9: per token  y = do_ln ? LN(g)*gamma+beta : g ;  eps = y W2^T + b2 ;
 //   x' = wrap_if_angle( c1[t] * (x - beta[t]*eps / c3[t]) + (t>0 ? sigma[t]*z : 0) )
@@ -150,6 +151,8 @@ struct AttnImgArgs {
   int B, H, LTOT, NKT, maxpos;
   float q_scale, k_scale, v_scale, ctx_scale;
   float r_scale;               // k_scale / scale of the distance table
+  float r_scale_k;             // q_scale / scale of the distance table (relative_key_query: the key term)
+  int rkq;                     // position_embedding_type == relative_key_query
   unsigned long long* stamps;  // null, or [4 waves][64 slots][8] cycle stamps of workgroup 0 (debug)
 };
 bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s);
