@@ -395,6 +395,7 @@ int ensure_ws(fd_model* m, int B, int L) {
     HIP_TRY(alz((void**)&w.aimg, cap * d * 4));
     HIP_TRY(alz((void**)&w.cimg, cap * d * 4));
     HIP_TRY(alz((void**)&w.gimg, cap * gmax * 4));
+    if (d > 384) HIP_TRY(alz((void**)&w.tmp, cap * d * 4));  // pre-LayerNorm fp32 rows (un-fused LayerNorm path)
     HIP_TRY(alz((void**)&w.qbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.vbuf, BH * w.LTOT * 128));
@@ -663,7 +664,13 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       g.A = w.cimg; g.W = static_cast<const unsigned char*>(lw.wo_i.p); g.bias = lw.bo; g.gamma = lw.ln1g; g.beta = lw.ln1b;
       g.resid = w.himg; g.out = w.aimg; g.N = d; g.K = d;
       g.acc_scale = 1.0f / (lw.s_v * lw.wo_i.scale); g.resid_inv = 1.0f / lw.s_h; g.out_scale = lw.s_a;
-      PROF(KC_GEMM_OUT, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
+      if (d <= 384) {
+        PROF(KC_GEMM_OUT, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
+      } else {  // a LayerNorm row does not fit one 384-column tile: fp32 rows, then the LayerNorm kernel
+        g.out_f32 = w.tmp;
+        PROF(KC_GEMM_OUT, launch_gemm_img(EPI_IMG_BIAS, g, max_rows, s));
+        PROF(KC_LN1, launch_ln_f32_img(w.tmp, lw.ln1g, lw.ln1b, c.ln_eps, w.dims, w.aimg, d, lw.s_a, max_rows, s));
+      }
       DBG_STOP();
     }
     {
@@ -678,7 +685,13 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       g.A = w.gimg; g.W = static_cast<const unsigned char*>(lw.wd_i.p); g.bias = lw.bd; g.gamma = lw.ln2g; g.beta = lw.ln2b;
       g.resid = w.aimg; g.out = w.himg; g.N = d; g.K = ff;
       g.acc_scale = 1.0f / (lw.s_g * lw.wd_i.scale); g.resid_inv = 1.0f / lw.s_a; g.out_scale = s_next;
-      PROF(KC_GEMM_DOWN, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
+      if (d <= 384) {
+        PROF(KC_GEMM_DOWN, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
+      } else {
+        g.out_f32 = w.tmp;
+        PROF(KC_GEMM_DOWN, launch_gemm_img(EPI_IMG_BIAS, g, max_rows, s));
+        PROF(KC_LN2, launch_ln_f32_img(w.tmp, lw.ln2g, lw.ln2b, c.ln_eps, w.dims, w.himg, d, s_next, max_rows, s));
+      }
       DBG_STOP();
     }
   }
@@ -977,10 +990,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
   free_weights(m);
   const fd_config& c = m->cfg;
   const size_t d = c.d_model, F = c.n_features, ff = c.d_ff;
-  // FD_PREC_F16X3 runs on the row-image kernels (LayerNorm rows must fit one 384-column workgroup tile);
-  // FDMI_IMG=0 keeps the previous register-staged split kernels (A/B knob)
-  if (precision == FD_PREC_F16X3 && d > 384)
-    return fail(FD_E_UNSUPPORTED, "FD_PREC_F16X3 fuses LayerNorm rows into one 384-column workgroup tile: d_model=%d > 384 needs FD_PREC_F32", (int)d);
+  // FD_PREC_F16X3 runs on the row-image kernels; the attention-output / FFN-down LayerNorm is fused into the GEMM when a row
+  // fits one 384-column workgroup tile (d_model <= 384: every released configuration), else it is its own launch
   const bool img = precision == FD_PREC_F16X3;
   m->img = img;
 #define NEED(var, nm)                         \

@@ -120,6 +120,7 @@ struct GemmImgArgs {
   const float* beta;           // [N]   EPI_IMG_LN
   const unsigned char* resid;  // image [rows128][N/32]   EPI_IMG_LN
   unsigned char* out;          // image [rows128][N/32]   EPI_IMG_GELU / EPI_IMG_LN
+  float* out_f32;              // EPI_IMG_BIAS only: when non-null the result (+ residual if `resid`) leaves as fp32 [rows128][N]
   unsigned char* qbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK
   unsigned char* kbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK (unit u of row l at u ^ ((l >> 1) & 7))
   unsigned char* vbuf;         // [B][H][LTOT / 32][32 d][128 B]  EPI_IMG_VT (V transposed, swizzled: gemm_img.hip)
@@ -179,6 +180,10 @@ struct HeadImgArgs {
 };
 // UpdateArgs: M = B * L (elements of one state / F), x / eps / noise / hist in the [B][L][F] layout.
 void launch_head_update_img(const UpdateArgs& a, const HeadImgArgs& ia, int max_rows, hipStream_t s);
+
+// y = LayerNorm(fp32 rows [rows128][d]) -> image (d_model > 384: the un-fused BertSelfOutput / BertOutput LayerNorm)
+void launch_ln_f32_img(const float* src, const float* gamma, const float* beta, float eps, const int* dims, void* out, int d,
+                       float out_scale, int max_rows, hipStream_t s);
 
 void launch_build_rows(const int* lens, int B, int L, int packed, int cap, int* seq_row0, int* nrow, int2* rowinfo,
                        int* dims, hipStream_t s);

@@ -299,6 +299,14 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     const int l31 = ln & 31, half = ln >> 5;
     const float os = p.acc_scale;
     const float* par0 = reinterpret_cast<const float*>(smem + OFF_PAR);
+    // bias of columns 32 cbg + 8 q + 4 half .. + 3 at scale sc: the LDS image holds the first 3 BN columns (already scaled);
+    // wider projections (d_model > 384) read the rest from global memory (cbg is wave-uniform)
+    auto bias4 = [&](int cbg, int q, float sc) -> float4 {
+      if (cbg * 32 < 3 * BN) return *reinterpret_cast<const float4*>(par0 + cbg * 32 + 8 * q + 4 * half);
+      float4 b = *reinterpret_cast<const float4*>(p.bias + cbg * 32 + 8 * q + 4 * half);
+      b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+      return b;
+    };
     if constexpr (EPI == EPI_IMG_GELU || EPI == EPI_IMG_BIAS) {
       const int nb = p.N >> 5;  // blocks per output row
 #pragma unroll
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         if (cb >= nb) continue;
         float4 b4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
+        for (int q = 0; q < 4; ++q) b4[q] = bias4(cb, q, 1.0f);
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -317,6 +325,24 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             o[4 * q + 1] = __builtin_fmaf(acc[jn][im][4 * q + 1], os, b4[q].y);
             o[4 * q + 2] = __builtin_fmaf(acc[jn][im][4 * q + 2], os, b4[q].z);
             o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3], os, b4[q].w);
+          }
+          if constexpr (EPI == EPI_IMG_BIAS) {
+            if (p.out_f32) {
+              // un-fused LayerNorm path (d_model > 384): dense + bias + residual leaves as fp32 rows for launch_ln_f32_img
+              if (p.resid) {
+                float rv[16];
+                u32x4 raw[4];
+                load_group_block_raw(p.resid + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, raw, l31, half);
+                unpack_block(raw, rv, p.resid_inv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] += rv[r];
+              }
+              float* dst = p.out_f32 + (size_t)(m0 + wm * 64 + im * 32 + l31) * p.N + cb * 32 + 4 * half;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+              continue;
+            }
           }
           if constexpr (EPI == EPI_IMG_GELU) {
 #pragma unroll
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         const int isk = cb >= H ? 1 : 0, h = cb - isk * H;
         float4 b4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(par0 + cb * 32 + 8 * q + 4 * half);
+        for (int q = 0; q < 4; ++q) b4[q] = bias4(cb, q, isk ? p.k_scale : p.q_scale);
         const float oss = os * (isk ? p.k_scale : p.q_scale);  // (the bias in LDS already carries the image's scale)
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
@@ -380,7 +406,8 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn - (merged ? 2 * H : 0);
         if (cb >= H) continue;
-        const float bz = par0[(cb + (merged ? 2 * H : 0)) * 32 + l31];
+        const int cbg = cb + (merged ? 2 * H : 0);
+        const float bz = cbg * 32 < 3 * BN ? par0[cbg * 32 + l31] : p.bias[cbg * 32 + l31] * p.v_scale;
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];

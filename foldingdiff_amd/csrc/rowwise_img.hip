@@ -8,8 +8,7 @@
 //                  (sampling.py:62-75), the per-feature wrap (sampling.py:119-130, utils.py:100-106), the history
 //                  row, the non-finite guard and the step counter
 //   f32 <-> image converters for the test hooks
-// 16 lanes per token: lane k owns the 4-column groups k + 16 j (256-byte coalesced group accesses of fp32 data,
-// 8-byte hi / lo pieces of an image block), row reductions are four DPP steps.
+// 16 lanes per token: lane k owns the 16-byte units k + 16 j of an image row (8 columns each), row reductions are four DPP steps.
 #include <cstdlib>
 
 #include "fdmi_kernels.h"
@@ -19,38 +18,70 @@ namespace fdmi {
 
 namespace {
 
-__device__ __forceinline__ float row16_sum(float v) {
+template <int LPT = 16>
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the LPT (8 or 16) neighbouring lanes of a token
 #define FD_DPP_ADD(ctrl) \
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
   FD_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
   FD_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
   FD_DPP_ADD(0x141);  // row_half_mirror
-  FD_DPP_ADD(0x140);  // row_mirror
+  if constexpr (LPT == 16) FD_DPP_ADD(0x140);  // row_mirror
 #undef FD_DPP_ADD
   return v;
 }
 
-// LayerNorm over the valid 4-column groups of a row spread over 16 lanes (biased variance, two passes)
-template <int NV>
-__device__ __forceinline__ void row16_layernorm(float4 (&v)[NV], const float4 (&gm)[NV], const float4 (&bt)[NV],
-                                                const bool (&ok)[NV], int d, float eps) {
+// ---- LPT (8 or 16) lanes per token, a lane owns whole 16-byte UNITS (8 columns: unit k + LPT j of the row): every image access is
+// a 16-byte hi piece + a 16-byte lo piece.  LPT = 8 (d_model <= 512): a wave holds 8 consecutive rows x 8 units, so each of
+// its store / load instructions touches whole 128-byte lines of the grouped image; LPT = 16 covers d_model <= 1024.
+// (Rounds 1-2 gave a lane 4-column groups = 8-byte pieces: 50 / 58 us for the two kernels against 32 / 42 us in fp32.)
+struct Unit8 {
+  float v[8];
+};
+// LayerNorm over the valid units of a row spread over 16 lanes (biased variance, two passes)
+template <int NV, int LPT>
+__device__ __forceinline__ void row16_layernorm(Unit8 (&x)[NV], const bool (&ok)[NV], int d, float eps, float& mean_out, float& rstd_out) {
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) s += ok[j] ? (v[j].x + v[j].y) + (v[j].z + v[j].w) : 0.f;
-  const float mean = row16_sum(s) / (float)d;
+  for (int j = 0; j < NV; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t += x[j].v[e];
+    s += ok[j] ? t : 0.f;
+  }
+  const float mean = row16_sum<LPT>(s) / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-    q += ok[j] ? (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w) : 0.f;
-  }
-  const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)d + eps);
+    float t = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    v[j].x = v[j].x * rstd * gm[j].x + bt[j].x;
-    v[j].y = v[j].y * rstd * gm[j].y + bt[j].y;
-    v[j].z = v[j].z * rstd * gm[j].z + bt[j].z;
-    v[j].w = v[j].w * rstd * gm[j].w + bt[j].w;
+    for (int e = 0; e < 8; ++e) {
+      x[j].v[e] -= mean;
+      t += x[j].v[e] * x[j].v[e];
+    }
+    q += ok[j] ? t : 0.f;
+  }
+  mean_out = mean;
+  rstd_out = 1.0f / sqrtf(row16_sum<LPT>(q) / (float)d + eps);
+}
+__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+// 8 values -> the unit's hi and lo 16-byte pieces (value * s = hi + lo)
+__device__ __forceinline__ void split8(const float (&v)[8], float s, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned h, l;
+    split_pair(v[2 * i] * s, v[2 * i + 1] * s, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+__device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float inv_s, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = (h2f_lo(hi[i]) + h2f_lo(lo[i])) * inv_s;
+    v[2 * i + 1] = (h2f_hi(hi[i]) + h2f_hi(lo[i])) * inv_s;
   }
 }
 
@@ -120,68 +151,124 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(const int* __restrict__ 
 }
 
 // ---------------------------------------------------------------- embed (K1)
-template <int NV>
+// LDS: w_in transposed [F][d], then b_in | gamma | beta | time embedding of this step ([4][d]): a lane reads its units' 8-column
+// slices from there per token (NV up to 8 units per lane: d <= 1024)
+template <int NV, int LPT>
 __global__ __launch_bounds__(256) void embed_img_kernel(EmbedImgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float wT[];  // [F][d]: w_in transposed
-  const int d = a.d, F = a.F, ng = d >> 2;
+  extern __shared__ __attribute__((aligned(16))) float wT[];  // [F][d] + [4][d]
+  const int d = a.d, F = a.F, nu = d >> 3;
+  float* par = wT + F * d;
+  const int t = a.tslot[0];
   for (int i = threadIdx.x; i < F * d; i += 256) {
     const int f = i / d, c = i - f * d;
     wT[i] = a.w_in[c * F + f];
   }
-  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int t = a.tslot[0];
+  for (int i = threadIdx.x; i < d; i += 256) {
+    par[i] = a.b_in[i];
+    par[d + i] = a.gamma[i];
+    par[2 * d + i] = a.beta[i];
+    par[3 * d + i] = a.time_table[(size_t)t * d + i];
+  }
+  const int k = threadIdx.x & (LPT - 1), g = threadIdx.x / LPT;
   if (blockIdx.x == 0 && threadIdx.x == 0) a.tslot[1] = t;  // the step's other kernels read slot 1 (see head_update_img)
-  float4 bi[NV], gm[NV], bt[NV], tt[NV];
   bool ok[NV];
+  int col[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    ok[j] = k + 16 * j < ng;
-    const int c = ok[j] ? 4 * (k + 16 * j) : 0;
-    bi[j] = *reinterpret_cast<const float4*>(a.b_in + c);
-    gm[j] = *reinterpret_cast<const float4*>(a.gamma + c);
-    bt[j] = *reinterpret_cast<const float4*>(a.beta + c);
-    tt[j] = *reinterpret_cast<const float4*>(a.time_table + (size_t)t * d + c);
+    ok[j] = k + LPT * j < nu;
+    col[j] = ok[j] ? 8 * (k + LPT * j) : 0;
   }
   __syncthreads();
   const int rows = a.dims[1];  // every row of the padded range is written (pad rows: zeros)
   const int nb = d >> 5;
-  for (int tg = blockIdx.x; tg * 16 < rows; tg += gridDim.x) {
-    const int row = tg * 16 + g;
+  for (int tg = blockIdx.x; tg * (256 / LPT) < rows; tg += gridDim.x) {
+    const int row = tg * (256 / LPT) + g;
     if (row >= rows) continue;  // (no barriers below)
     const int2 ri = a.rowinfo[row];
     const bool real = ri.x >= 0 && ri.y < a.nrow[ri.x >= 0 ? ri.x : 0];
     const size_t xo = real ? ((size_t)ri.x * a.L + ri.y) * F : 0;
-    float4 v[NV];
+    Unit8 v[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = bi[j];
+    for (int j = 0; j < NV; ++j) load8(par + col[j], v[j].v);
     for (int f = 0; f < F; ++f) {
       const float xf = a.x[xo + f];
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const float4 w = *reinterpret_cast<const float4*>(wT + f * d + (ok[j] ? 4 * (k + 16 * j) : 0));
-        v[j].x += xf * w.x; v[j].y += xf * w.y; v[j].z += xf * w.z; v[j].w += xf * w.w;
+        float w[8];
+        load8(wT + f * d + col[j], w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j].v[e] += xf * w[e];
       }
     }
     if (a.pos_emb) {  // absolute positions only (modelling.py:164-166)
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const float4 pe = *reinterpret_cast<const float4*>(a.pos_emb + (size_t)(real ? ri.y : 0) * d + (ok[j] ? 4 * (k + 16 * j) : 0));
-        v[j].x += pe.x; v[j].y += pe.y; v[j].z += pe.z; v[j].w += pe.w;
+        float pe[8];
+        load8(a.pos_emb + (size_t)(real ? ri.y : 0) * d + col[j], pe);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j].v[e] += pe[e];
       }
     }
-    row16_layernorm<NV>(v, gm, bt, ok, d, a.eps);
+    float mean, rstd;
+    row16_layernorm<NV, LPT>(v, ok, d, a.eps, mean, rstd);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       if (!ok[j]) continue;
-      const int grp = k + 16 * j;
+      float gm[8], bt[8], tt[8], o[8];
+      load8(par + d + col[j], gm);
+      load8(par + 2 * d + col[j], bt);
+      load8(par + 3 * d + col[j], tt);
       // time embedding added AFTER the LayerNorm (modelling.py:472); pad rows are zero rows
-      const float4 o = real ? make_float4(v[j].x + tt[j].x, v[j].y + tt[j].y, v[j].z + tt[j].z, v[j].w + tt[j].w)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-      u32x2 hi, lo;
-      split4(o, a.out_scale, hi, lo);
-      unsigned char* blk = a.h + img_unit_offset(row, nb, grp >> 3, (grp & 7) >> 1) + 8 * (grp & 1);  // 4 columns = half a unit
-      *reinterpret_cast<u32x2*>(blk) = hi;
-      *reinterpret_cast<u32x2*>(blk + 4 * 512) = lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = real ? (v[j].v[e] * rstd * gm[e] + bt[e]) + tt[e] : 0.f;
+      u32x4 hi, lo;
+      split8(o, a.out_scale, hi, lo);
+      const int u = k + LPT * j;
+      unsigned char* blk = a.h + img_unit_offset(row, nb, u >> 2, u & 3);
+      *reinterpret_cast<u32x4*>(blk) = hi;
+      *reinterpret_cast<u32x4*>(blk + 4 * 512) = lo;
+    }
+  }
+}
+
+// LayerNorm of fp32 rows -> image (models with d_model > 384: the LayerNorm row does not fit one 384-column GEMM tile, so the
+// projection writes dense + bias + residual as fp32 rows and this kernel normalises them; BertSelfOutput / BertOutput)
+template <int NV, int LPT>
+__global__ __launch_bounds__(256) void ln_f32_img_kernel(const float* __restrict__ src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, const int* __restrict__ dims,
+                                                          unsigned char* __restrict__ out, int d, float out_scale) {
+  const int nu = d >> 3, nb = d >> 5;
+  const int k = threadIdx.x & (LPT - 1), g = threadIdx.x / LPT;
+  bool ok[NV];
+  int col[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    ok[j] = k + LPT * j < nu;
+    col[j] = ok[j] ? 8 * (k + LPT * j) : 0;
+  }
+  const int rows = dims[1];
+  for (int tg = blockIdx.x; tg * (256 / LPT) < rows; tg += gridDim.x) {
+    const int row = tg * (256 / LPT) + g;
+    if (row >= rows) continue;
+    Unit8 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) load8(src + (size_t)row * d + col[j], v[j].v);
+    float mean, rstd;
+    row16_layernorm<NV, LPT>(v, ok, d, eps, mean, rstd);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (!ok[j]) continue;
+      float gm[8], bt[8], o[8];
+      load8(gamma + col[j], gm);
+      load8(beta + col[j], bt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = v[j].v[e] * rstd * gm[e] + bt[e];
+      u32x4 hi, lo;
+      split8(o, out_scale, hi, lo);
+      const int u = k + LPT * j;
+      unsigned char* blk = out + img_unit_offset(row, nb, u >> 2, u & 3);
+      *reinterpret_cast<u32x4*>(blk) = hi;
+      *reinterpret_cast<u32x4*>(blk + 4 * 512) = lo;
     }
   }
 }
@@ -227,20 +314,23 @@ __device__ __forceinline__ float wrap_pi(float v) {
 }
 
 // ---------------------------------------------------------------- head tail + p_sample update (K8/K9)
-template <int NV>
+template <int NV, int LPT>
 __global__ __launch_bounds__(256) void head_update_img_kernel(UpdateArgs a, HeadImgArgs ia) {
   extern __shared__ __attribute__((aligned(16))) float w2s[];  // [F][d]
-  const int d = a.d, F = a.F, ng = d >> 2, nb = d >> 5;
+  const int d = a.d, F = a.F, nu = d >> 3, nb = d >> 5;
+  float* par = w2s + F * d;  // gamma | beta
   for (int i = threadIdx.x; i < F * d; i += 256) w2s[i] = a.w2[i];
-  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
-  float4 gm[NV], bt[NV];
+  for (int i = threadIdx.x; i < d; i += 256) {
+    par[i] = a.do_ln ? a.gamma[i] : 1.f;
+    par[d + i] = a.do_ln ? a.beta[i] : 0.f;
+  }
+  const int k = threadIdx.x & (LPT - 1), g = threadIdx.x / LPT;
   bool ok[NV];
+  int col[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    ok[j] = k + 16 * j < ng;
-    const int c = ok[j] ? 4 * (k + 16 * j) : 0;
-    gm[j] = a.do_ln ? *reinterpret_cast<const float4*>(a.gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-    bt[j] = a.do_ln ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ok[j] = k + LPT * j < nu;
+    col[j] = ok[j] ? 8 * (k + LPT * j) : 0;
   }
   const float b2k = a.b2[k < F ? k : 0];
   // per-call values (see UpdateDyn)
@@ -260,28 +350,43 @@ __global__ __launch_bounds__(256) void head_update_img_kernel(UpdateArgs a, Head
   const int rows = ia.dims[0];
   const size_t BLF = (size_t)a.M * F;  // elements of one [B][L][F] state (a.M = B * L)
   bool bad = false;
-  for (int tg = blockIdx.x; tg * 16 < rows; tg += gridDim.x) {
-    const int row = tg * 16 + g;
+  for (int tg = blockIdx.x; tg * (256 / LPT) < rows; tg += gridDim.x) {
+    const int row = tg * (256 / LPT) + g;
     const int2 ri = row < rows ? ia.rowinfo[row] : make_int2(-1, -1);
     const bool real = ri.x >= 0 && ri.y < ia.nrow[ri.x >= 0 ? ri.x : 0];
     const int grow = row < rows ? row : 0;
-    float4 v[NV];
+    Unit8 v[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int grp = ok[j] ? k + 16 * j : 0;
-      const unsigned char* blk = ia.g + img_unit_offset(grow, nb, grp >> 3, (grp & 7) >> 1) + 8 * (grp & 1);
-      v[j] = join4(*reinterpret_cast<const u32x2*>(blk), *reinterpret_cast<const u32x2*>(blk + 4 * 512), ia.g_inv);
+      const int u = ok[j] ? k + LPT * j : 0;
+      const unsigned char* blk = ia.g + img_unit_offset(grow, nb, u >> 2, u & 3);
+      join8(*reinterpret_cast<const u32x4*>(blk), *reinterpret_cast<const u32x4*>(blk + 4 * 512), ia.g_inv, v[j].v);
     }
-    if (a.do_ln) row16_layernorm<NV>(v, gm, bt, ok, d, a.ln_eps);
+    if (a.do_ln) {
+      float mean, rstd;
+      row16_layernorm<NV, LPT>(v, ok, d, a.ln_eps, mean, rstd);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        float gm[8], bt[8];
+        load8(par + col[j], gm);
+        load8(par + d + col[j], bt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j].v[e] = v[j].v[e] * rstd * gm[e] + bt[e];
+      }
+    }
     float mine = 0.f;
     for (int f = 0; f < F; ++f) {
       float partial = 0.f;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const float4 w = *reinterpret_cast<const float4*>(w2s + f * d + (ok[j] ? 4 * (k + 16 * j) : 0));
-        partial += ok[j] ? (v[j].x * w.x + v[j].y * w.y) + (v[j].z * w.z + v[j].w * w.w) : 0.f;
+        float w[8];
+        load8(w2s + f * d + col[j], w);
+        float pj = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) pj += v[j].v[e] * w[e] + v[j].v[e + 1] * w[e + 1];
+        partial += ok[j] ? pj : 0.f;
       }
-      partial = row16_sum(partial);
+      partial = row16_sum<LPT>(partial);
       mine = (k == f) ? partial + b2k : mine;
     }
     if (k < F && real) {
@@ -374,25 +479,65 @@ void launch_build_rows(const int* lens, int B, int L, int packed, int cap, int* 
   hipLaunchKernelGGL(fill_rows_kernel, dim3(grid), dim3(256), 0, s, seq_row0, B, cap, rowinfo);
 }
 
+// lanes per token: 8 when the row fits 8 lanes x 8 units (and, for the head kernel, a lane per output feature), else 16
+#define FD_ROW_SWITCH(KERNEL, ...)                                                                              \
+  do {                                                                                                          \
+    if (lpt == 8) {                                                                                             \
+      switch (nv) {                                                                                             \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        case 2: hipLaunchKernelGGL((KERNEL<2, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        case 3: hipLaunchKernelGGL((KERNEL<3, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        case 5: hipLaunchKernelGGL((KERNEL<5, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        case 6: hipLaunchKernelGGL((KERNEL<6, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        case 7: hipLaunchKernelGGL((KERNEL<7, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+        default: hipLaunchKernelGGL((KERNEL<8, 8>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;       \
+      }                                                                                                         \
+    }                                                                                                           \
+    switch (nv) {                                                                                               \
+      case 1: hipLaunchKernelGGL((KERNEL<1, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      case 2: hipLaunchKernelGGL((KERNEL<2, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      case 3: hipLaunchKernelGGL((KERNEL<3, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      case 4: hipLaunchKernelGGL((KERNEL<4, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      case 5: hipLaunchKernelGGL((KERNEL<5, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      case 6: hipLaunchKernelGGL((KERNEL<6, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      case 7: hipLaunchKernelGGL((KERNEL<7, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;         \
+      default: hipLaunchKernelGGL((KERNEL<8, 16>), dim3(grid), dim3(256), smem, s, __VA_ARGS__); return;        \
+    }                                                                                                           \
+  } while (0)
+
+static int row_grid(int max_rows, int lpt) {  // blocks of the grid-stride row kernels (each block first fills its LDS parameter image)
+  static const int cap = [] { const char* e = getenv("FDMI_ROW_GRID"); return e ? atoi(e) : 1024; }();
+  const int per = 256 / lpt;
+  int grid = (max_rows + per - 1) / per;
+  return grid > cap ? cap : (grid < 1 ? 1 : grid);
+}
+static int row_lpt(int d, int F) {  // F > 0: the head kernel (one lane per output feature; measured faster with 16 lanes at d = 384)
+  static const int force = [] { const char* e = getenv("FDMI_ROW_LPT"); return e ? atoi(e) : 0; }();
+  if (force == 16 || d > 512 || F > 8) return 16;
+  if (force == 8) return 8;
+  return F > 0 ? 16 : 8;
+}
+
 void launch_embed_img(const EmbedImgArgs& a, int max_rows, hipStream_t s) {
-  int grid = (max_rows + 15) / 16;
-  if (grid > 2048) grid = 2048;
-  const size_t smem = (size_t)a.F * a.d * 4;
-  const int nv = (a.d / 4 + 15) / 16;
-#define FD_EI(NV) case NV: hipLaunchKernelGGL((embed_img_kernel<NV>), dim3(grid), dim3(256), smem, s, a); return;
-  switch (nv) { FD_EI(1) FD_EI(2) FD_EI(3) FD_EI(4) FD_EI(5) FD_EI(6) }
-#undef FD_EI
+  const int lpt = row_lpt(a.d, 0), nv = (a.d / 8 + lpt - 1) / lpt, grid = row_grid(max_rows, lpt);
+  const size_t smem = (size_t)(a.F + 4) * a.d * 4;
+  FD_ROW_SWITCH(embed_img_kernel, a);
 }
 
 void launch_head_update_img(const UpdateArgs& a, const HeadImgArgs& ia, int max_rows, hipStream_t s) {
-  int grid = (max_rows + 15) / 16;
-  if (grid > 2048) grid = 2048;
-  const size_t smem = (size_t)a.F * a.d * 4;
-  const int nv = (a.d / 4 + 15) / 16;
-#define FD_HI(NV) case NV: hipLaunchKernelGGL((head_update_img_kernel<NV>), dim3(grid), dim3(256), smem, s, a, ia); return;
-  switch (nv) { FD_HI(1) FD_HI(2) FD_HI(3) FD_HI(4) FD_HI(5) FD_HI(6) }
-#undef FD_HI
+  const int lpt = row_lpt(a.d, a.F), nv = (a.d / 8 + lpt - 1) / lpt, grid = row_grid(max_rows, lpt);
+  const size_t smem = (size_t)(a.F + 2) * a.d * 4;
+  FD_ROW_SWITCH(head_update_img_kernel, a, ia);
 }
+
+void launch_ln_f32_img(const float* src, const float* gamma, const float* beta, float eps, const int* dims, void* out, int d,
+                       float out_scale, int max_rows, hipStream_t s) {
+  const int lpt = row_lpt(d, 0), nv = (d / 8 + lpt - 1) / lpt, grid = row_grid(max_rows, lpt);
+  const size_t smem = 0;
+  FD_ROW_SWITCH(ln_f32_img_kernel, src, gamma, beta, eps, dims, static_cast<unsigned char*>(out), d, out_scale);
+}
+#undef FD_ROW_SWITCH
 
 void launch_f32_to_img(const float* src, void* dst, long long rows, int K, long long src_rows, float scale, hipStream_t s) {
   hipLaunchKernelGGL(f32_to_img_kernel, dim3(blocks_for(rows * (K / 4))), dim3(256), 0, s, src,

@@ -355,10 +355,6 @@ class BertForDiffusionBase:
         assert len(is_angle) == self.n_inputs
         if self.precision not in _binding.FD_PREC:
             raise ValueError(f"precision={self.precision!r}; expected one of {sorted(_binding.FD_PREC)}")
-        if self.precision == "f16x3" and self.config.hidden_size > 384:
-            # the split path fuses whole LayerNorm rows into one 384-column workgroup tile
-            logging.warning("hidden_size=%d > 384: using the exact-fp32 kernels (precision 'f32')", self.config.hidden_size)
-            self.precision = "f32"
         key = (betas.numel(), betas.numpy().tobytes(), tuple(bool(a) for a in is_angle), self.precision)
         if self._betas_key == key:
             return h
