@@ -77,18 +77,20 @@ def main(argv=None) -> None:
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    outdir = Path(args.outdir)
+    # every check that can fail is made BEFORE the process group exists: a rank that raises behind init_process_group leaves the
+    # others blocked in the first collective until the RCCL timeout
+    assert os.path.isdir(args.model), f"{args.model} is not a local model directory (there is no network access here)"
+    if rank == 0:
+        os.makedirs(outdir, exist_ok=True)
+        # Be extra cautious so we don't overwrite any results (bin/sample.py:299)
+        assert not os.listdir(outdir), f"Expected {outdir} to be empty!"
     if world > 1:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         args.device = f"cuda:{local_rank}"
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(args.device))
-    outdir = Path(args.outdir)
-    if rank == 0:
-        os.makedirs(outdir, exist_ok=True)
-        # Be extra cautious so we don't overwrite any results (bin/sample.py:299)
-        assert not os.listdir(outdir), f"Expected {outdir} to be empty!"
-    assert os.path.isdir(args.model), f"{args.model} is not a local model directory (there is no network access here)"
 
     train_dset = build_datasets(Path(args.model))
     model = modelling.BertForDiffusionBase.from_dir(

@@ -1127,7 +1127,10 @@ int fd_set_option(fd_model* m, const char* name, int value) {
     m->split_qkv = value ? 1 : 0;
     drop_workspaces(m);  // captured graphs hold the other launch sequence
   }
-  else if (n == "debug_stop") m->debug_stop = value;
+  else if (n == "debug_stop") {
+    if (m->debug_stop != value) drop_workspaces(m);  // a graph captured with a truncated step must not be replayed afterwards
+    m->debug_stop = value;
+  }
   else if (n == "debug_layer") m->debug_layer = value;
   else return fail(FD_E_INVALID, "unknown option '%s'", name);
   return FD_OK;

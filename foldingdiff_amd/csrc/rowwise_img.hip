@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void build_rows_kernel(const int* __restrict_
   const int b0 = tid * per, b1 = b0 + per < B ? b0 + per : B;
   int s = 0;
   for (int b = b0; b < b1; ++b) {
-    const int n = packed ? lens[b] : L;
+    const int n = packed ? min(max(lens[b], 1), L) : L;  // (device-resident lengths are not validated by the host)
     s += (n + 7) & ~7;
   }
   part[tid] = s;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024) void build_rows_kernel(const int* __restrict_
   __syncthreads();
   int run = part[tid];
   for (int b = b0; b < b1; ++b) {
-    const int n = packed ? lens[b] : L;
+    const int n = packed ? min(max(lens[b], 1), L) : L;  // (device-resident lengths are not validated by the host)
     seq_row0[b] = run;
     nrow[b] = n;
     run += (n + 7) & ~7;

@@ -88,6 +88,15 @@ def all_gather_batches(local: torch.Tensor, counts: Sequence[int], device=None, 
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0).to(home)
 
 
+def any_rank_failed(failed: bool, device=None, group=None) -> bool:
+    """True on every rank iff some rank reports a failure (one scalar all-reduce).  A rank that raised in front of a
+    collective would leave the others blocked in it until the backend's timeout."""
+    on = device if (dist.get_backend(group) == "nccl" and device is not None) else torch.device("cpu")
+    flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=on)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(flag.item()))
+
+
 def sample_sharded(
     run_local: Callable[[int, int], torch.Tensor],
     n_items: int,

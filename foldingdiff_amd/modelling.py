@@ -412,7 +412,11 @@ class BertForDiffusionBase:
             # the reference honours position_ids with absolute embeddings (modelling.py:434-442); the device kernels
             # always use 0 .. L-1 -- refuse anything else instead of silently computing a different function
             want = torch.arange(inputs.shape[1]).expand(inputs.shape[0], -1)
-            if tuple(position_ids.shape) != tuple(want.shape) or not torch.equal(position_ids.detach().cpu().long(), want):
+            try:  # (a broadcastable (1, L) / (L,) arange is what callers usually pass)
+                same = torch.equal(torch.broadcast_to(position_ids.detach().cpu().long(), want.shape), want)
+            except RuntimeError:
+                same = False
+            if not same:
                 raise NotImplementedError("position_ids other than arange(seq_len) are not supported")
         lens = self.lengths_from_mask(attention_mask)
         t = timestep.detach().cpu().reshape(-1).long()

@@ -383,6 +383,7 @@ def sample(
         bounds = fdist.shard_by_tokens(these, world) if world > 1 else [(0, B)]
         lo, hi = bounds[rank]
         rows = 1 if final_only else -(-T // history_every)
+        local_error = None
         if hi > lo:
             prev_varlen = model.set_option("varlen", 1)
             try:
@@ -391,6 +392,11 @@ def sample(
                     betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
                     disable_pbar=disable_pbar, final_only=final_only, history_every=history_every,
                     seed=seed, seq_offset=lo, draw_batch=(B, lo, hi))
+            except Exception as e:  # e.g. FD_E_NONFINITE from this rank's slice: every rank must learn of it before the gather
+                if world == 1:
+                    raise
+                local_error = e
+                traj = torch.zeros((rows, hi - lo, L, F), dtype=torch.float32)
             finally:
                 model.set_option("varlen", prev_varlen if prev_varlen is not None else 0)
         else:
@@ -399,6 +405,9 @@ def sample(
             traj = torch.zeros((rows, 0, L, F), dtype=torch.float32)
         if world > 1:  # the single exchange of the path: [b_r, rows, L, F] blocks -> every rank holds the whole batch
             device = getattr(model, "device", torch.device("cpu"))
+            failed = fdist.any_rank_failed(local_error is not None, device)   # one tiny all-reduce: all ranks abort together
+            if failed:
+                raise RuntimeError(f"rank {rank}: sampling failed on " + ("this rank: " + repr(local_error) if local_error else "another rank"))
             full = fdist.all_gather_batches(traj.permute(1, 0, 2, 3).contiguous(), [h_ - l_ for l_, h_ in bounds], device)
             traj = full.permute(1, 0, 2, 3)
         results.extend(traj[:, i, :l, :].numpy().copy() for i, l in enumerate(these))

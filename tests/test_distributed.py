@@ -147,3 +147,46 @@ def test_sample_is_sharded_and_world_size_invariant(mode):
         assert len(got[rank]) == 27
         for a, b in zip(got[rank], want):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from foldingdiff_amd import datasets, sampling
+
+        def stub(h, x0, lens, t_start, zs, seed, seq_offset, out, full_history):
+            if dist.get_rank() == 1:
+                raise ValueError("non-finite prediction on this rank's slice")
+            _stub_fd_sample(h, x0, lens, t_start, zs, seed, seq_offset, out, full_history)
+
+        sampling._run_fd_sample = stub
+        sampling.NOISE_MODE = "philox"
+        ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=32), timesteps=4,
+                                          beta_schedule="cosine")
+        torch.manual_seed(11)
+        try:
+            sampling.sample(_StubModel(), ds, n=3, sweep_lengths=(5, 9), batch_size=16, final_only=True)
+            q.put((rank, "returned"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_aborts_every_rank():
+    """A rank whose slice fails must not leave the others blocked in the gather: the error flag is all-reduced first and
+    every rank raises."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "this rank" in got[1] and "non-finite" in got[1]
+    assert "another rank" in got[0]
