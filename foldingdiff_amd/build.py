@@ -25,7 +25,11 @@ HEADERS = [os.path.join(CSRC, "fdmi_kernels.h"), os.path.join(CSRC, "img_common.
            os.path.join(os.path.dirname(PKG_DIR), "include", "fdmi.h")]
 ARCH = "gfx950"
 # flags of single sources (see the header of the source for the reason)
-PER_SOURCE_FLAGS = {}
+PER_SOURCE_FLAGS = {
+    # packed fp32 VALU instructions (v_pk_fma_f32 ...) serialize with the matrix pipe, plain ones issue beside another wave's
+    # MFMAs (profiles/r03_coissue2_probe.log): the staggered attention schedule needs un-packed softmax / skew arithmetic
+    "attention_img": ["-fno-slp-vectorize"],
+}
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 

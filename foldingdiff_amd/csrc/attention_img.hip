@@ -27,8 +27,16 @@
 #include "fdmi_kernels.h"
 #include "img_common.h"
 
+#include <type_traits>
+
+#ifndef FDMI_ATTN_STAG
+#define FDMI_ATTN_STAG 1  // the two wave groups of a workgroup run half a position apart (0: in lockstep, as in round 2)
+#endif
+
 namespace fdmi {
 namespace ai {
+
+template <int V> using IC = std::integral_constant<int, V>;
 
 
 constexpr float PS = 1024.0f;  // probabilities are <= 1
@@ -65,6 +73,15 @@ struct Geo {
 template <int T, bool REL, bool ELDS, int NG, bool SAFE, bool PROF = false, bool RKQ = false>
 __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   static_assert(REL || !RKQ, "relative_key_query is a relative position type");
+  // STAG: group 1 runs HALF A POSITION behind group 0.  A position is two halves of three barrier-separated segments each:
+  //     H1  [A] S^T tiles + band tiles [0, B1)  |  band tiles [B1, B2)  |  band tiles [B2, T]           (matrix heavy)
+  //     H2  [B] issue K(p+1), softmax           |  [C] P V              |  [D] issue V(p+1), ctx store  (VALU heavy)
+  // so on every SIMD one wave is in H1 while the other is in H2: the plain fp32 VALU instructions of the one issue beside the
+  // MFMAs of the other (profiles/r03_coissue2_probe.log; this file is compiled with -fno-slp-vectorize, packed fp32 would
+  // serialize with the matrix pipe).  In lockstep both waves of a SIMD ran the same phase and the matrix pipe idled through
+  // every softmax (29 % MFMA utilisation, cycle stamps).  Group 1 starts with an empty half, group 0 ends with one.
+  constexpr bool STAG = FDMI_ATTN_STAG != 0 && NG == 2;
+  constexpr int B1 = 1, B2 = T >= 3 ? 3 : 2;  // band tile runs (T + 1 tiles)
   using G = Geo<T, ELDS>;
   constexpr int LP = G::LP;
   constexpr int GSZ = REL ? G::G_REL : G::G_ABS;
@@ -193,6 +210,14 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
+  if constexpr (STAG) {
+    if (grp == 1) {  // (its copies of the distance table must have landed before group 0 reads the table behind this barrier)
+      FD_WAIT_VM(G::VW);
+      barrier_keep_vm();
+      barrier_keep_vm();
+      barrier_keep_vm();
+    }
+  }
   for (int iter = 0; iter < niter; ++iter) {
     FD_STAMP(0);
     const bool live = iter < my_len;  // this group still has positions (otherwise it only keeps the barriers company)
@@ -227,6 +252,134 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
 
     f32x16 sacc[T];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- relative_key band (used inside the `active` blocks below)
+    // R tile q: rows = queries rowmap(r, half), cols = band index 32 q + l31 (band origin: this wave's row
+    // block).  S^T tile t element (key kl, query ql) needs band column j = ql - kl + 31 of the tile pair
+    // (q = T-1-t, q+1): j < 32 -> tile q, else tile q+1 column j-32.  Band row of R tile q, column l31:
+    //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + 32 q + l31, clamped: rows outside the table are only
+    // ever paired with padding keys / queries (L <= maxpos).
+    auto band_tile = [&](auto QQ) {
+      constexpr int qq = decltype(QQ)::value;
+      int m = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * qq;
+      m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
+      u32x4 e0, e1, e2, e3;  // units half, 2 + half (hi d 0-15 / 16-31), 4 + half, 6 + half (lo)
+      if constexpr (ELDS) {
+        const unsigned char* erow = Es + m * 128;
+        const int sz = (m >> 1) & 7;
+        e0 = *reinterpret_cast<const u32x4*>(erow + ((half ^ sz) << 4));
+        e1 = *reinterpret_cast<const u32x4*>(erow + (((2 + half) ^ sz) << 4));
+        e2 = *reinterpret_cast<const u32x4*>(erow + (((4 + half) ^ sz) << 4));
+        e3 = *reinterpret_cast<const u32x4*>(erow + (((6 + half) ^ sz) << 4));
+      } else {
+        const u32x4_t* erow = p.demb + (size_t)m * 8;
+        e0 = erow[half]; e1 = erow[2 + half]; e2 = erow[4 + half]; e3 = erow[6 + half];
+      }
+      f32x16 racc;
+      {
+        const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
+        const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], eh0, zero16, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], el0, racc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[0], eh0, racc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], eh1, racc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], el1, racc, 0, 0, 0);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[1], eh1, racc, 0, 0, 0);
+      }
+      // scratch layout [register r][lane] (R row 8q + 4 half + e of lane-column l31 at r * 256 + lane * 4): the 16 stores
+      // are ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR: 2 LDS cycles instead of 4)
+      {
+        unsigned keep;
+        asm volatile(
+            // (the MFMA results need 12 wait states before a non-MFMA reader: hipcc pads nothing inside an asm statement)
+            "s_nop 7\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 2\n\t"
+            "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
+            "ds_write_addtid_b32 %3 offset:512\n\tds_write_addtid_b32 %4 offset:768\n\t"
+            "ds_write_addtid_b32 %5 offset:1024\n\tds_write_addtid_b32 %6 offset:1280\n\t"
+            "ds_write_addtid_b32 %7 offset:1536\n\tds_write_addtid_b32 %8 offset:1792\n\t"
+            "ds_write_addtid_b32 %9 offset:2048\n\tds_write_addtid_b32 %10 offset:2304\n\t"
+            "ds_write_addtid_b32 %11 offset:2560\n\tds_write_addtid_b32 %12 offset:2816\n\t"
+            "ds_write_addtid_b32 %13 offset:3072\n\tds_write_addtid_b32 %14 offset:3328\n\t"
+            "ds_write_addtid_b32 %15 offset:3584\n\tds_write_addtid_b32 %16 offset:3840\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(racc[0]), "v"(racc[1]), "v"(racc[2]), "v"(racc[3]), "v"(racc[4]), "v"(racc[5]), "v"(racc[6]), "v"(racc[7]),
+              "v"(racc[8]), "v"(racc[9]), "v"(racc[10]), "v"(racc[11]), "v"(racc[12]), "v"(racc[13]), "v"(racc[14]), "v"(racc[15]),
+              "s"(rw_lds)
+            : "memory");
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // scratch row = query l31 (this lane); band column j = l31 - kl + 31 of the tile PAIR lives in tile q for
+      // j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise: both read scratch column j & 31
+      float gth[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        gth[r] = Rrow[(l31 - kl + 31) & 31];
+      }
+      // band weights bw_lo / bw_hi (r_ratio where the element belongs to the lower / upper tile of the pair, else 0): one
+      // fma per element and tile instead of a select + fma (band values are finite MFMA sums, so 0 * value = 0)
+      if (qq < T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[T - 1 - qq][r] = __builtin_fmaf(gth[r], bw_lo[r], sacc[T - 1 - qq][r]);
+      }
+      if (qq > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[T - qq][r] = __builtin_fmaf(gth[r], bw_hi[r], sacc[T - qq][r]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next band tile overwrites this scratch
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (RKQ) {
+        // the key term against the SAME band tile: S^T tile T-1-qq takes it as its lower tile, S^T tile T-qq as its upper one
+        const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
+        const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
+        const float rk = p.r_scale_k / p.r_scale;  // band weights carry r_scale (k_scale / table scale); this term needs q_scale / table scale
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const int t = side == 0 ? T - 1 - qq : T - qq;
+          if (t < 0 || t >= T) continue;
+          const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
+          const int ksz = (l31 >> 3) & 1;
+          const f16x8 kh0 = *reinterpret_cast<const f16x8*>(pc + (((0 + half) ^ ksz) << 7));
+          const f16x8 kl0 = *reinterpret_cast<const f16x8*>(pc + (((4 + half) ^ ksz) << 7));
+          const f16x8 kh1 = *reinterpret_cast<const f16x8*>(pc + (((2 + half) ^ ksz) << 7));
+          const f16x8 kl1 = *reinterpret_cast<const f16x8*>(pc + (((6 + half) ^ ksz) << 7));
+          f32x16 kacc;
+          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, eh0, zero16, 0, 0, 0);
+          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, el0, kacc, 0, 0, 0);
+          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, eh0, kacc, 0, 0, 0);
+          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, eh1, kacc, 0, 0, 0);
+          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, el1, kacc, 0, 0, 0);
+          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, eh1, kacc, 0, 0, 0);
+          // scratch [register r][lane]: row (key) 8q + 4 half + e of column l31 at r * 256 + lane * 4 (as above, plain stores)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Rw[r * 64 + lane] = kacc[r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float g = Rw[r * 64 + half * 32 + ((l31 - kl + 31) & 31)] * rk;
+            sacc[t][r] = __builtin_fmaf(g, side == 0 ? bw_lo[r] : bw_hi[r], sacc[t][r]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    };
+    // band tiles 0 .. T in three runs [0, B1) [B1, B2) [B2, T]: the staggered schedule puts a workgroup barrier between them
+    auto band_run = [&](auto LO, auto HI) {
+      constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+      if constexpr (lo < hi && lo <= T) {
+        band_tile(IC<lo>{});
+        if constexpr (lo + 1 < hi && lo + 1 <= T) band_tile(IC<lo + 1>{});
+        if constexpr (lo + 2 < hi && lo + 2 <= T) band_tile(IC<lo + 2>{});
+        if constexpr (lo + 3 < hi && lo + 3 <= T) band_tile(IC<lo + 3>{});
+        if constexpr (lo + 4 < hi && lo + 4 <= T) band_tile(IC<lo + 4>{});
+      }
+    };
     if (active) {
       // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale)
 #pragma unroll
@@ -244,124 +397,16 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
         }
       }
-      if constexpr (REL) {
-        // R tile q: rows = queries rowmap(r, half), cols = band index 32 q + l31 (band origin: this wave's row
-        // block).  S^T tile t element (key kl, query ql) needs band column j = ql - kl + 31 of the tile pair
-        // (q = T-1-t, q+1): j < 32 -> tile q, else tile q+1 column j-32.  Band row of R tile q, column l31:
-        //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + 32 q + l31, clamped: rows outside the table are only
-        // ever paired with padding keys / queries (L <= maxpos).
-#pragma unroll
-        for (int qq = 0; qq <= T; ++qq) {
-          int m = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * qq;
-          m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
-          u32x4 e0, e1, e2, e3;  // units half, 2 + half (hi d 0-15 / 16-31), 4 + half, 6 + half (lo)
-          if constexpr (ELDS) {
-            const unsigned char* erow = Es + m * 128;
-            const int sz = (m >> 1) & 7;
-            e0 = *reinterpret_cast<const u32x4*>(erow + ((half ^ sz) << 4));
-            e1 = *reinterpret_cast<const u32x4*>(erow + (((2 + half) ^ sz) << 4));
-            e2 = *reinterpret_cast<const u32x4*>(erow + (((4 + half) ^ sz) << 4));
-            e3 = *reinterpret_cast<const u32x4*>(erow + (((6 + half) ^ sz) << 4));
-          } else {
-            const u32x4_t* erow = p.demb + (size_t)m * 8;
-            e0 = erow[half]; e1 = erow[2 + half]; e2 = erow[4 + half]; e3 = erow[6 + half];
-          }
-          f32x16 racc;
-          {
-            const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
-            const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], eh0, zero16, 0, 0, 0);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], el0, racc, 0, 0, 0);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[0], eh0, racc, 0, 0, 0);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], eh1, racc, 0, 0, 0);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], el1, racc, 0, 0, 0);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[1], eh1, racc, 0, 0, 0);
-          }
-          // scratch layout [register r][lane] (R row 8q + 4 half + e of lane-column l31 at r * 256 + lane * 4): the 16 stores
-          // are ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR: 2 LDS cycles instead of 4)
-          {
-            unsigned keep;
-            asm volatile(
-                // (the MFMA results need 12 wait states before a non-MFMA reader: hipcc pads nothing inside an asm statement)
-                "s_nop 7\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 2\n\t"
-                "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
-                "ds_write_addtid_b32 %3 offset:512\n\tds_write_addtid_b32 %4 offset:768\n\t"
-                "ds_write_addtid_b32 %5 offset:1024\n\tds_write_addtid_b32 %6 offset:1280\n\t"
-                "ds_write_addtid_b32 %7 offset:1536\n\tds_write_addtid_b32 %8 offset:1792\n\t"
-                "ds_write_addtid_b32 %9 offset:2048\n\tds_write_addtid_b32 %10 offset:2304\n\t"
-                "ds_write_addtid_b32 %11 offset:2560\n\tds_write_addtid_b32 %12 offset:2816\n\t"
-                "ds_write_addtid_b32 %13 offset:3072\n\tds_write_addtid_b32 %14 offset:3328\n\t"
-                "ds_write_addtid_b32 %15 offset:3584\n\tds_write_addtid_b32 %16 offset:3840\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(racc[0]), "v"(racc[1]), "v"(racc[2]), "v"(racc[3]), "v"(racc[4]), "v"(racc[5]), "v"(racc[6]), "v"(racc[7]),
-                  "v"(racc[8]), "v"(racc[9]), "v"(racc[10]), "v"(racc[11]), "v"(racc[12]), "v"(racc[13]), "v"(racc[14]), "v"(racc[15]),
-                  "s"(rw_lds)
-                : "memory");
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          // scratch row = query l31 (this lane); band column j = l31 - kl + 31 of the tile PAIR lives in tile q for
-          // j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise: both read scratch column j & 31
-          float gth[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            gth[r] = Rrow[(l31 - kl + 31) & 31];
-          }
-          // band weights bw_lo / bw_hi (r_ratio where the element belongs to the lower / upper tile of the pair, else 0): one
-          // fma per element and tile instead of a select + fma (band values are finite MFMA sums, so 0 * value = 0)
-          if (qq < T) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[T - 1 - qq][r] = __builtin_fmaf(gth[r], bw_lo[r], sacc[T - 1 - qq][r]);
-          }
-          if (qq > 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[T - qq][r] = __builtin_fmaf(gth[r], bw_hi[r], sacc[T - qq][r]);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next band tile overwrites this scratch
-          __builtin_amdgcn_wave_barrier();
-          if constexpr (RKQ) {
-            // the key term against the SAME band tile: S^T tile T-1-qq takes it as its lower tile, S^T tile T-qq as its upper one
-            const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
-            const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
-            const float rk = p.r_scale_k / p.r_scale;  // band weights carry r_scale (k_scale / table scale); this term needs q_scale / table scale
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-              const int t = side == 0 ? T - 1 - qq : T - qq;
-              if (t < 0 || t >= T) continue;
-              const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
-              const int ksz = (l31 >> 3) & 1;
-              const f16x8 kh0 = *reinterpret_cast<const f16x8*>(pc + (((0 + half) ^ ksz) << 7));
-              const f16x8 kl0 = *reinterpret_cast<const f16x8*>(pc + (((4 + half) ^ ksz) << 7));
-              const f16x8 kh1 = *reinterpret_cast<const f16x8*>(pc + (((2 + half) ^ ksz) << 7));
-              const f16x8 kl1 = *reinterpret_cast<const f16x8*>(pc + (((6 + half) ^ ksz) << 7));
-              f32x16 kacc;
-              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, eh0, zero16, 0, 0, 0);
-              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, el0, kacc, 0, 0, 0);
-              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, eh0, kacc, 0, 0, 0);
-              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, eh1, kacc, 0, 0, 0);
-              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, el1, kacc, 0, 0, 0);
-              kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, eh1, kacc, 0, 0, 0);
-              // scratch [register r][lane]: row (key) 8q + 4 half + e of column l31 at r * 256 + lane * 4 (as above, plain stores)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) Rw[r * 64 + lane] = kacc[r];
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float g = Rw[r * 64 + half * 32 + ((l31 - kl + 31) & 31)] * rk;
-                sacc[t][r] = __builtin_fmaf(g, side == 0 ? bw_lo[r] : bw_hi[r], sacc[t][r]);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-            }
-          }
-        }
-      }
+      if constexpr (REL) band_run(IC<0>{}, IC<B1>{});
+    }
+
+    if constexpr (STAG) barrier_keep_vm();  // (staggered schedule: three segments per half position, see the kernel header)
+    if constexpr (REL) {
+      if (active) band_run(IC<B1>{}, IC<B2>{});
+    }
+    if constexpr (STAG) barrier_keep_vm();
+    if constexpr (REL) {
+      if (active) band_run(IC<B2>{}, IC<T + 1>{});
     }
 
     // ---- [B] every wave is done with K: copy the next position's K, fetch the next item's Q
@@ -481,6 +526,13 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     }
   }
 #undef FD_STAMP
+  if constexpr (STAG) {
+    if (grp == 0) {
+      barrier_keep_vm();
+      barrier_keep_vm();
+      barrier_keep_vm();
+    }
+  }
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
