@@ -58,6 +58,10 @@ _SIGNATURES = {
     "fd_sample_begin_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, _P, C.c_int, _P]),
     "fd_sample_steps_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "fd_sample_end_dev": (C.c_int, [_P, _P, _P]),
+    "fd_comm_unique_id": (C.c_int, [_P]),
+    "fd_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "fd_gather_dev": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    "fd_comm_destroy": (C.c_int, [_P]),
     "fd_philox_normal_dev": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P]),
     "fd_nerf": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "fd_test_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),

@@ -2,6 +2,7 @@
 // hipGraph-captured reverse-diffusion loop and the measurement hooks.
 // Boundary: include/fdmi.h (each entry point cites the reference function it replaces).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -135,6 +136,8 @@ struct fd_model {
   std::vector<Workspace> cache;
   uint64_t use_clock = 0;
   Workspace ws;      // the current one (moved in and out of `cache`)
+  void* comm = nullptr;  // ncclComm_t (fd_comm_init)
+  int comm_world = 0, comm_rank = 0;
   UpdateDyn dyn_host{};  // per-run values of the sampling loop in progress (fd_sample_begin_dev .. fd_sample_end_dev)
   int run_t = -1;        // next timestep of that run (-1: none left)
   // profiling
@@ -916,8 +919,95 @@ int img_gemm_hook(int epilogue, const float* A, const float* W, const float* bia
 
 }  // namespace
 
+// ---- RCCL, bound at run time (dlopen): the library has no link-time dependency on it, and a host process that already
+// carries an RCCL (PyTorch does) shares that instance.  Only what the single gather of SURVEY 8(e) needs.
+namespace {
+struct RcclId {
+  char internal[128];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+      r.GetUniqueId = reinterpret_cast<int (*)(RcclId*)>(dlsym(r.lib, "ncclGetUniqueId"));
+      r.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclId, int)>(dlsym(r.lib, "ncclCommInitRank"));
+      r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.lib, "ncclAllGather"));
+      r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(r.lib, "ncclGetErrorString"));
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.lib = nullptr;
+    }
+  }
+  return r.lib ? &r : nullptr;
+}
+int rccl_fail(const char* what, int rc) {
+  Rccl* r = rccl();
+  return fail(FD_E_HIP, "%s failed: %s", what, (r && r->GetErrorString) ? r->GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
 // ============================================================================ C ABI
 extern "C" {
+
+int fd_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(FD_E_INVALID, "null argument");
+  Rccl* r = rccl();
+  if (!r) return fail(FD_E_UNSUPPORTED, "librccl.so could not be loaded");
+  RcclId id;
+  if (int rc = r->GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(id_out, &id, sizeof id);
+  return FD_OK;
+}
+
+int fd_comm_init(fd_model* m, int rank, int world, const void* unique_id) {
+  if (!m || !unique_id) return fail(FD_E_INVALID, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(FD_E_INVALID, "rank %d of %d", rank, world);
+  Rccl* r = rccl();
+  if (!r) return fail(FD_E_UNSUPPORTED, "librccl.so could not be loaded");
+  HIP_TRY(hipSetDevice(m->device));
+  if (m->comm) {
+    (void)r->CommDestroy(m->comm);
+    m->comm = nullptr;
+  }
+  RcclId id;
+  memcpy(&id, unique_id, sizeof id);
+  if (int rc = r->CommInitRank(&m->comm, world, id, rank)) return rccl_fail("ncclCommInitRank", rc);
+  m->comm_world = world;
+  m->comm_rank = rank;
+  return FD_OK;
+}
+
+int fd_comm_destroy(fd_model* m) {
+  if (!m) return fail(FD_E_INVALID, "null argument");
+  Rccl* r = rccl();
+  if (m->comm && r) (void)r->CommDestroy(m->comm);
+  m->comm = nullptr;
+  m->comm_world = 0;
+  return FD_OK;
+}
+
+int fd_gather_dev(fd_model* m, const void* local_dev, int64_t n_floats, void* out_dev, void* hip_stream) {
+  if (!m || !local_dev || !out_dev || n_floats < 0) return fail(FD_E_INVALID, "bad argument");
+  if (!m->comm) return fail(FD_E_STATE, "fd_comm_init has not been called");
+  Rccl* r = rccl();
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  if (int rc = r->AllGather(local_dev, out_dev, (size_t)n_floats, /*ncclFloat*/ 7, m->comm, s)) return rccl_fail("ncclAllGather", rc);
+  return FD_OK;
+}
 
 int fd_abi_version(void) { return FDMI_ABI_VERSION; }
 
@@ -1105,6 +1195,7 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
 void fd_destroy(fd_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
+  (void)fd_comm_destroy(m);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   drop_workspaces(m);
   free_weights(m);

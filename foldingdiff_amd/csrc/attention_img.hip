@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   // serialize with the matrix pipe).  In lockstep both waves of a SIMD ran the same phase and the matrix pipe idled through
   // every softmax (29 % MFMA utilisation, cycle stamps).  Group 1 starts with an empty half, group 0 ends with one.
   constexpr bool STAG = FDMI_ATTN_STAG != 0 && NG == 2;
-  constexpr int B1 = 1, B2 = T >= 3 ? 3 : 2;  // band tile runs (T + 1 tiles)
+#ifndef FDMI_ATTN_B1
+#define FDMI_ATTN_B1 1
+#define FDMI_ATTN_B2 3
+#endif
+  constexpr int B1 = T >= 3 ? FDMI_ATTN_B1 : 1, B2 = T >= 3 ? FDMI_ATTN_B2 : 2;  // band tile runs (T + 1 tiles)
   using G = Geo<T, ELDS>;
   constexpr int LP = G::LP;
   constexpr int GSZ = REL ? G::G_REL : G::G_ABS;

@@ -184,6 +184,21 @@ int fd_sample_begin_dev(fd_model* m, const void* x_init_dev, const void* lens_de
 int fd_sample_steps_dev(fd_model* m, int n_steps, const void* noise_dev, int noise_t0, void* hip_stream);
 int fd_sample_end_dev(fd_model* m, void* out_dev, void* hip_stream);
 
+/* ---- multi-GPU through the ABI: independent sequences are sharded across the GPUs of a node by the HOST (one
+ * model per GPU, each sampling its slice with seq_offset = its first global sequence index; Philox noise is keyed by that
+ * index, so results do not depend on the world size) and ONE collective returns the slices: an RCCL all-gather over xGMI.
+ * The reference has no multi-GPU sampler (foldingdiff/sampling.py:91 is single-device); the Python package does the same
+ * exchange through torch.distributed (foldingdiff_amd/distributed.py).  RCCL is bound at run time (dlopen librccl.so).
+ *   fd_comm_unique_id  128 bytes, created by one process and distributed by the host (file, pipe, MPI ...)
+ *   fd_comm_init       joins the communicator (collective over all ranks); one communicator per model
+ *   fd_gather_dev      out_dev[r * n_floats ...] = rank r's local_dev[0 .. n_floats) for every r; equal counts on every rank
+ *                      (pad ragged slices to the largest); stream-ordered on hip_stream (NULL: the model's stream) */
+#define FD_COMM_ID_BYTES 128
+int fd_comm_unique_id(void* id_out);
+int fd_comm_init(fd_model* m, int rank, int world, const void* unique_id);
+int fd_gather_dev(fd_model* m, const void* local_dev, int64_t n_floats, void* out_dev, void* hip_stream);
+int fd_comm_destroy(fd_model* m);
+
 /* Fill out_dev[n] (device, float32) with the Philox N(0,1) stream used for step
  * t of a [B][L][F] batch -- exposes the perf-mode generator for tests. */
 int fd_philox_normal_dev(fd_model* m, uint64_t seed, int t, int64_t seq_offset, int B, int L, void* out_dev,
