@@ -24,11 +24,11 @@ if [ "${WITH_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel-trace --stats (same command as the bench, T=${PROF_T:-200})"
   R=$PWD
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 1 --warmup 0 --timesteps ${PROF_T:-200} --no-cpu-baseline --no-exact-f32 --no-c5-extra ${BENCH_ARGS:-} > $R/$OUT/prof_run.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 1 --warmup 0 --timesteps ${PROF_T:-200} --no-cpu-baseline --no-exact-f32 --no-c5-extra --no-user-paths ${BENCH_ARGS:-} > $R/$OUT/prof_run.log 2>&1
   tail -1 $R/$OUT/prof_run.log | cut -c1-400
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== rocprofv3 --pmc $c (eager launches, T=4)"
-    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 4 --profile-every 0 --no-cpu-baseline --no-exact-f32 --no-c5-extra ${BENCH_ARGS:-} > $R/$OUT/pmc_$c.log 2>&1
+    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 4 --profile-every 0 --no-cpu-baseline --no-exact-f32 --no-c5-extra --no-user-paths ${BENCH_ARGS:-} > $R/$OUT/pmc_$c.log 2>&1
     tail -1 $R/$OUT/pmc_$c.log | cut -c1-200
   done
   cd $R
@@ -42,7 +42,7 @@ if [ -n "${PMC_EXTRA:-}" ]; then
   IFS=';' read -ra SETS <<< "$PMC_EXTRA"
   for set in "${SETS[@]}"; do
     i=$((i+1)); echo "== rocprofv3 --pmc $set"
-    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pmcx_$i -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 3 --profile-every 0 --no-cpu-baseline --no-exact-f32 --no-c5-extra ${BENCH_ARGS:-} > $R/$OUT/pmcx_$i.log 2>&1
+    FDMI_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pmcx_$i -o pmc -- python $R/bench.py --steps 1 --warmup 0 --timesteps 3 --profile-every 0 --no-cpu-baseline --no-exact-f32 --no-c5-extra --no-user-paths ${BENCH_ARGS:-} > $R/$OUT/pmcx_$i.log 2>&1
     tail -1 $R/$OUT/pmcx_$i.log | cut -c1-160
   done
   cd $R
