@@ -353,8 +353,7 @@ def main():
         for mode in ("philox", "torch"):
             sampling.NOISE_MODE = mode
             torch.manual_seed(7344)
-            if mode == "philox":  # first call of these (B, L): workspaces + graph capture, not timed
-                sampling.sample(model, ds, n=1, sweep_lengths=(100, 102), batch_size=512, final_only=True)
+            if mode == "philox":  # first call of these two (B, L) shapes: workspaces + graph capture, not timed
                 sampling.sample(model, ds, n=10, sweep_lengths=(50, 128), batch_size=512, final_only=True)
                 torch.manual_seed(7344)
             t3 = time.perf_counter()
