@@ -144,9 +144,14 @@ def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start:
     lib = _binding.load()
     B, L, F = x0.shape
     nrow = min(NOISE_CHUNK, t_start + 1)
-    pinned = [torch.empty((nrow, B, L, F), dtype=torch.float32).pin_memory() for _ in range(2)]
-    dbuf = [torch.empty((nrow, B, L, F), dtype=torch.float32, device=dev) for _ in range(2)]
-    copy_s, run_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    key = (nrow, B, L, F, str(dev))
+    if key not in _NOISE_BUFFERS:  # (page-locking 2 x 50 MB costs more than a chunk's upload: keep the buffers of the last few shapes)
+        while len(_NOISE_BUFFERS) >= 4:
+            _NOISE_BUFFERS.pop(next(iter(_NOISE_BUFFERS)))
+        _NOISE_BUFFERS[key] = ([torch.empty((nrow, B, L, F), dtype=torch.float32).pin_memory() for _ in range(2)],
+                               [torch.empty((nrow, B, L, F), dtype=torch.float32, device=dev) for _ in range(2)],
+                               torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    pinned, dbuf, copy_s, run_s = _NOISE_BUFFERS[key]
     copied = [torch.cuda.Event(), torch.cuda.Event()]
     consumed = [None, None]
     x_d = torch.from_numpy(x0).to(dev)
@@ -195,6 +200,7 @@ def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start:
 
 
 _run_fd_sample_default = _run_fd_sample
+_NOISE_BUFFERS: dict = {}
 
 
 @torch.no_grad()
