@@ -8,7 +8,7 @@
 //           conflict-free 16-byte operand fetches), copied with per-lane source offsets: eight neighbouring lanes read the
 //           eight rows of one unit = one 128-byte line
 //     vt  [b][h][32-key block][32 d][128 B]    V transposed: hi keys | lo keys as sixteen 8-byte units, unit u stored
-//                                               at u ^ ((d >> 1) & 15)  (conflict-free 8-byte operand fetches)
+//                                               at u ^ vt_swz(d)  (img_common.h: conflict-free 8-byte operand fetches)
 // so filling LDS is a linear LDS-DMA copy: no VGPR round trip, no split arithmetic, no ds_write.
 //
 // One 8-wave workgroup per CU, persistent; its waves form two 4-wave groups, each walking its own stream of
@@ -81,6 +81,9 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   // serialize with the matrix pipe).  In lockstep both waves of a SIMD ran the same phase and the matrix pipe idled through
   // every softmax (29 % MFMA utilisation, cycle stamps).  Group 1 starts with an empty half, group 0 ends with one.
   constexpr bool STAG = FDMI_ATTN_STAG != 0 && NG == 2;
+#ifndef FDMI_ATTN_DBG
+#define FDMI_ATTN_DBG 0  // ablation builds (wrong results): linear LDS addresses for 1 the V reads, 2 the K reads, 4 the skew gather, 8 the table reads, 16 plain scratch stores
+#endif
 #ifndef FDMI_ATTN_B1
 #define FDMI_ATTN_B1 1
 #define FDMI_ATTN_B2 3
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
       u32x4 e0, e1, e2, e3;  // units half, 2 + half (hi d 0-15 / 16-31), 4 + half, 6 + half (lo)
       if constexpr (ELDS) {
-        const unsigned char* erow = Es + m * 128;
-        const int sz = (m >> 1) & 7;
+        const unsigned char* erow = (FDMI_ATTN_DBG & 8) ? Es + qq * 4096 + l31 * 16 : Es + m * 128;
+        const int sz = (FDMI_ATTN_DBG & 8) ? 0 : (m >> 1) & 7;
         e0 = *reinterpret_cast<const u32x4*>(erow + ((half ^ sz) << 4));
         e1 = *reinterpret_cast<const u32x4*>(erow + (((2 + half) ^ sz) << 4));
         e2 = *reinterpret_cast<const u32x4*>(erow + (((4 + half) ^ sz) << 4));
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-        gth[r] = Rrow[(l31 - kl + 31) & 31];
+        gth[r] = (FDMI_ATTN_DBG & 4) ? Rw[r * 64 + lane] : Rrow[(l31 - kl + 31) & 31];
       }
       // band weights bw_lo / bw_hi (r_ratio where the element belongs to the lower / upper tile of the pair, else 0): one
       // fma per element and tile instead of a select + fma (band values are finite MFMA sums, so 0 * value = 0)
@@ -389,8 +392,8 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
-        const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
-        const int ksz = (l31 >> 3) & 1;
+        const unsigned char* pc = (FDMI_ATTN_DBG & 2) ? Ks + t * 4096 + lane * 16 : Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
+        const int ksz = (FDMI_ATTN_DBG & 2) ? 0 : (l31 >> 3) & 1;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const f16x8 kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     if (active) {
       // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],  B = P (registers),
       //                   key(c, half, j) = 32 t + 16 c + 8 (j>>2) + 4 half + (j&3)   (the C/D row map)
-      const unsigned char* vrow = Vt + (size_t)l31 * 128;
-      const int sz = (l31 >> 1) & 15;
+      const unsigned char* vrow = (FDMI_ATTN_DBG & 1) ? Vt + lane * 8 : Vt + (size_t)l31 * 128;
+      const int sz = (FDMI_ATTN_DBG & 1) ? 0 : vt_swz(l31);
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll

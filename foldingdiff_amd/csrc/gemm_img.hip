@@ -393,13 +393,13 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       // 32-row MFMA tile.  After the exchange the lower lane holds token octets 0, 1 and the upper lane 2, 3 of the
       // tile; sequences start at multiples of 8 rows, so an octet never straddles two sequences.
       // V^T block layout: [b][h][key block l/32][d][128 B = sixteen 8-byte units: hi keys 4u..4u+3 (u < 8) | lo],
-      // unit u stored at position u ^ ((d >> 1) & 15) (conflict-free 8-byte LDS fetches in the attention kernel
+      // unit u stored at position u ^ vt_swz(d) (img_common.h: conflict-free 8-byte LDS fetches in the attention kernel
       // after a linear LDS-DMA copy); an octet = one aligned 16-byte pair of units, halves swapped when the
       // swizzle is odd -- so every store is an aligned 16-byte piece of a 128-byte line, as in the q / k epilogue.
       const int H = p.H, nkb = p.LTOT >> 5;
       FD_WAIT_VM(0);  // the row info landed long ago; the wave has nothing else in flight
       const int2* rinfo = reinterpret_cast<const int2*>(smem + OFF_RI + wid * 512);
-      const int sz = (l31 >> 1) & 15;
+      const int sz = vt_swz(l31);
       const float osv = os * p.v_scale;  // (the bias in LDS already carries the image's scale)
       constexpr bool merged = EPI == EPI_IMG_QKV;  // v columns follow the 2 H blocks of q | k
 #pragma unroll

@@ -449,8 +449,8 @@ __global__ void qkv_unpack_kernel(const unsigned char* __restrict__ src, float* 
     const long long bh = row / LTOT;
     const int l = (int)(row - bh * LTOT);
     const _Float16 *hp, *lp;
-    if (is_vt == 1) {  // [bh][l / 32][d][128 B], 8-byte unit u at position u ^ ((d >> 1) & 15)
-      const int kb = l >> 5, kl = l & 31, sz = (dd >> 1) & 15;
+    if (is_vt == 1) {  // [bh][l / 32][d][128 B], 8-byte unit u at position u ^ vt_swz(d)
+      const int kb = l >> 5, kl = l & 31, sz = vt_swz(dd);
       const unsigned char* r = src + (((bh * (LTOT >> 5) + kb) * 32) + dd) * (size_t)128;
       hp = reinterpret_cast<const _Float16*>(r + (((kl >> 2) ^ sz) << 3)) + (kl & 3);
       lp = reinterpret_cast<const _Float16*>(r + (((8 + (kl >> 2)) ^ sz) << 3)) + (kl & 3);
