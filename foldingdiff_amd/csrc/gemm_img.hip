@@ -345,14 +345,27 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             }
           }
           if constexpr (EPI == EPI_IMG_GELU) {
+#ifdef FDMI_GELU_PAIRS  // A/B build: the pair form of rounds 2-3 (the scale is then applied here instead of inside)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              const gf2 g = gelu_erf2(gf2{o[r], o[r + 1]});
+              const gf2 g = gelu_erf2(gf2{o[r], o[r + 1]}) * p.out_scale;
               o[r] = g[0];
               o[r + 1] = g[1];
             }
+#else
+            const float hs = 0.5f * p.out_scale;  // the GELU leaves at the output image's scale
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+              const gf4 g = gelu_erf4_scaled(gf4{o[r], o[r + 1], o[r + 2], o[r + 3]}, hs);
+              o[r] = g[0];
+              o[r + 1] = g[1];
+              o[r + 2] = g[2];
+              o[r + 3] = g[3];
+            }
+#endif
           }
-          store_group_block(p.out + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, o, p.out_scale, l31, half);
+          store_group_block(p.out + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, o, EPI == EPI_IMG_GELU ? 1.0f : p.out_scale,
+                            l31, half);
         }
       }
     } else if constexpr (kQK) {

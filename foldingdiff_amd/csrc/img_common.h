@@ -264,4 +264,30 @@ __device__ __forceinline__ gf2 gelu_erf2(gf2 x) {
   const gf2 e = (p * y) * r;
   return __builtin_elementwise_fma(h, e, h);
 }
+// four elements at a time, result already multiplied by the output image's scale (hs = 0.5 * scale, a power of two: the same bits
+// as scale * gelu).  Two independent element pairs per step: consecutive packed instructions do not depend on each other, so the
+// one wait state a dependent v_pk_* needs costs no s_nop (39 of them per 32 x 32 block in the pair form, ISA listing).
+typedef float gf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gf4 gelu_erf4_scaled(gf4 x, float hs) {
+  const gf4 h = x * hs;
+  gf4 y = x * 0.70710678118654752440f;
+  auto c = [](float v) { return gf4{v, v, v, v}; };
+  y = __builtin_elementwise_min(__builtin_elementwise_max(y, c(-4.0f)), c(4.0f));
+  const gf4 y2 = y * y;
+  gf4 p = c(-2.72614225801306e-10f);
+  p = __builtin_elementwise_fma(p, y2, c(2.77068142495902e-08f));
+  p = __builtin_elementwise_fma(p, y2, c(-2.10102402082508e-06f));
+  p = __builtin_elementwise_fma(p, y2, c(-5.69250639462346e-05f));
+  p = __builtin_elementwise_fma(p, y2, c(-7.34990630326855e-04f));
+  p = __builtin_elementwise_fma(p, y2, c(-2.95459980854025e-03f));
+  p = __builtin_elementwise_fma(p, y2, c(-1.60960333262415e-02f));
+  gf4 q = c(-1.45660718464996e-05f);
+  q = __builtin_elementwise_fma(q, y2, c(-2.13374055278905e-04f));
+  q = __builtin_elementwise_fma(q, y2, c(-1.68282697438203e-03f));
+  q = __builtin_elementwise_fma(q, y2, c(-7.37332916720468e-03f));
+  q = __builtin_elementwise_fma(q, y2, c(-1.42647390514189e-02f));
+  const gf4 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1]), __builtin_amdgcn_rcpf(q[2]), __builtin_amdgcn_rcpf(q[3])};
+  const gf4 e = (p * y) * r;
+  return __builtin_elementwise_fma(h, e, h);
+}
 }  // namespace fdmi
