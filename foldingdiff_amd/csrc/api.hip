@@ -399,6 +399,9 @@ int ensure_ws(fd_model* m, int B, int L) {
     HIP_TRY(alz((void**)&w.cimg, cap * d * 4));
     HIP_TRY(alz((void**)&w.gimg, cap * gmax * 4));
     if (d > 384) HIP_TRY(alz((void**)&w.tmp, cap * d * 4));  // pre-LayerNorm fp32 rows (un-fused LayerNorm path)
+    if (BH * w.LTOT * 128 >= (1ull << 32))
+      return fail(FD_E_UNSUPPORTED, "B=%lld x heads x L=%d: the q / k / v images of one batch must stay below 4 GiB; use smaller batches",
+                  (long long)B, (int)L);
     HIP_TRY(alz((void**)&w.qbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.vbuf, BH * w.LTOT * 128));
@@ -612,6 +615,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     memset(&g, 0, sizeof g);
     g.stamps = m->stamps;
     g.trash = w.trash; g.rowinfo = w.rowinfo; g.dims = w.dims;
+    g.qkv_bytes = (unsigned)((size_t)w.B * H * w.LTOT * 128);
     g.H = H; g.LPK = w.LPK; g.LTOT = w.LTOT; g.NKT = w.NKT;
     g.eps = c.ln_eps;
     return g;

@@ -125,6 +125,7 @@ struct GemmImgArgs {
   unsigned char* kbuf;         // [B][H][LTOT][128 B]     EPI_IMG_QK (unit u of row l at u ^ ((l >> 1) & 7))
   unsigned char* vbuf;         // [B][H][LTOT / 32][32 d][128 B]  EPI_IMG_VT (V transposed, swizzled: gemm_img.hip)
   unsigned char* trash;        // >= 256 B scratch line for the stores of padding rows
+  unsigned qkv_bytes;          // size of each of qbuf / kbuf / vbuf (< 4 GiB: the q | k | v epilogues address them with 32-bit offsets)
   const int2* rowinfo;
   const int* dims;
   int N, K;                    // valid output columns (multiple of 32), reduction length (multiple of 32)

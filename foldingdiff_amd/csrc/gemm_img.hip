@@ -372,9 +372,19 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       const int H = p.H;
       FD_WAIT_VM(0);  // the row info landed long ago; the wave has nothing else in flight
       const int2* rinfo = reinterpret_cast<const int2*>(smem + OFF_RI + wid * 512);
-      int2 ri[2];
+      // q and k are grouped images per (sequence, head): [position / 32][unit][position % 32][16 B].  The lane's byte offset
+      // inside the image of head 0 is computed ONCE per tile and row; the head's share (h LTOT 128 B) rides in the scalar offset
+      // of the buffer stores.  Rows that are no token (alignment / tail rows) get an offset beyond the buffer: the hardware drops
+      // their stores -- no predication, no 64-bit address arithmetic per block (it was ~40 of a block's ~190 VALU instructions).
+      unsigned roff[2];
 #pragma unroll
-      for (int im = 0; im < 2; ++im) ri[im] = rinfo[im * 32 + l31];
+      for (int im = 0; im < 2; ++im) {
+        const int2 ri = rinfo[im * 32 + l31];
+        roff[im] = ri.x >= 0 ? (unsigned)ri.x * (unsigned)(H * p.LTOT * 128) + (unsigned)((ri.y >> 5) * 4096 + (ri.y & 31) * 16 + half * 1024)
+                             : 0xFFFFF000u;
+      }
+      const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(p.qbuf, 0, p.qkv_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(p.kbuf, 0, p.qkv_bytes, 0x00020000);
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn;  // wave-uniform: block of the [q | k] column space
@@ -384,6 +394,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = bias4(cb, q, isk ? p.k_scale : p.q_scale);
         const float oss = os * (isk ? p.k_scale : p.q_scale);  // (the bias in LDS already carries the image's scale)
+        const int hoff = h * p.LTOT * 128;
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -394,11 +405,26 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
             o[4 * q + 2] = __builtin_fmaf(acc[jn][im][4 * q + 2], oss, b4[q].z);
             o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3], oss, b4[q].w);
           }
-          // q and k are grouped images per (sequence, head): [position / 32][unit][position % 32][16 B]; rows that are
-          // no token (alignment / tail rows) are not stored
-          const bool ok = ri[im].x >= 0;
-          // (sequence, head) base folded into the row index of a one-block-per-row image: row = (b H + h) LTOT + position
-          store_block_g(isk ? p.kbuf : p.qbuf, 1, ok ? ((long long)ri[im].x * H + h) * p.LTOT + ri[im].y : 0, 0, o, 1.0f, half, ok);
+          u32x4 h0, h1, l0, l1;
+          pack_block(o, 1.0f, h0, h1, l0, l1);
+          if (FDMI_EPI_DBG == 1) {
+            asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1));
+            continue;
+          }
+          // (plain stores: write-through ones made the q | k | v projection 13 % slower)
+          if (isk) {
+            __builtin_amdgcn_raw_buffer_store_b128(h0, rsk, (int)roff[im], hoff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(h1, rsk, (int)roff[im], hoff + 512, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(l0, rsk, (int)roff[im], hoff + 2048, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(l1, rsk, (int)roff[im], hoff + 2560, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(h0, rsq, (int)roff[im], hoff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(h1, rsq, (int)roff[im], hoff + 512, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(l0, rsq, (int)roff[im], hoff + 2048, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(l1, rsq, (int)roff[im], hoff + 2560, 0);
+          }
+          store_guard(h0, h1);
+          store_guard(l0, l1);
         }
       }
     } else if constexpr (kVT) {
@@ -415,12 +441,27 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       const int sz = vt_swz(l31);
       const float osv = os * p.v_scale;  // (the bias in LDS already carries the image's scale)
       constexpr bool merged = EPI == EPI_IMG_QKV;  // v columns follow the 2 H blocks of q | k
+      // byte offset of the lane's hi octet inside the V^T image of head 0, once per tile and token octet (im, u); the head's share
+      // rides in the scalar offset; octets of rows that are no token get an offset beyond the buffer (dropped by the hardware)
+      unsigned voff[2][2], voffl[2][2];  // (hi octet, lo octet = four 16-byte pairs further: the hi offset ^ 64, oc < 4)
+#pragma unroll
+      for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int2 ri = rinfo[im * 32 + 16 * half + 8 * u];
+          const int kb = ri.y >> 5, oc = (ri.y & 31) >> 3;
+          voff[im][u] = ri.x >= 0 ? ((unsigned)ri.x * (unsigned)(H * nkb) + (unsigned)kb) * 4096u + (unsigned)(l31 * 128 + ((oc ^ (sz >> 1)) << 4))
+                                  : 0xFFFFF000u;
+          voffl[im][u] = voff[im][u] ^ 64u;
+        }
+      const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(p.vbuf, 0, p.qkv_bytes, 0x00020000);
 #pragma unroll
       for (int jn = 0; jn < 3; ++jn) {
         const int cb = (n0 >> 5) + wn * 3 + jn - (merged ? 2 * H : 0);
         if (cb >= H) continue;
         const int cbg = cb + (merged ? 2 * H : 0);
         const float bz = cbg * 32 < 3 * BN ? par0[cbg * 32 + l31] : p.bias[cbg * 32 + l31] * p.v_scale;
+        const int hoff = cb * nkb * 4096;
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
           float o[16];
@@ -430,18 +471,18 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           pack_block(o, 1.0f, hh[0], hh[1], ll[0], ll[1]);
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int2 ri = rinfo[im * 32 + 16 * half + 8 * u];
-            const bool ok = ri.x >= 0;
-            const int lpos = ok ? ri.y : 0;
-            const int kb = lpos >> 5, oc = (lpos & 31) >> 3;
             u32x4 vh = hh[u], vl = ll[u];
             if (sz & 1) {
               vh = u32x4{vh[2], vh[3], vh[0], vh[1]};
               vl = u32x4{vl[2], vl[3], vl[0], vl[1]};
             }
-            unsigned char* row = ok ? p.vbuf + ((((size_t)ri.x * H + cb) * nkb + kb) * 32 + l31) * 128 : p.trash;
-            *reinterpret_cast<u32x4*>(row + ((oc ^ (sz >> 1)) << 4)) = vh;
-            *reinterpret_cast<u32x4*>(row + (((4 + oc) ^ (sz >> 1)) << 4)) = vl;
+            if (FDMI_EPI_DBG == 1) {
+              asm volatile("" ::"v"(vh), "v"(vl));
+              continue;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(vh, rsv, (int)voff[im][u], hoff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(vl, rsv, (int)voffl[im][u], hoff, 0);
+            store_guard(vh, vl);
           }
         }
       }

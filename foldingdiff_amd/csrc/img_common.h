@@ -105,6 +105,12 @@ __device__ __forceinline__ void quad_oct_exchange(unsigned (&X)[8]) {
   swap32(X[5], X[7]);
 }
 
+// Behind a group of 16-byte buffer stores: keeps their data registers alive (and one wait state away from the next VALU write)
+// until the stores have been issued.  A VALU write of a store's data VGPR in the very next instruction corrupted stored
+// dwords on gfx950 (seen once with `v_xor` recomputing an address INTO a data register right behind buffer_store_dwordx4,
+// profiles/r03_gemm_notes.log); hipcc only pads that hazard for stores without an SGPR offset.
+__device__ __forceinline__ void store_guard(const u32x4& a, const u32x4& b) { asm volatile("s_nop 0" ::"v"(a), "v"(b)); }
+
 // (x0, x1) -> hi = fp16 pair of (x0, x1), lo = fp16 pair of (x - hi).  v_fma_mixlo/mixhi_f16 take the fp32 x and the fp16 hi
 // operand directly: x * 1.0 - hi is exact in fp32 and rounded once -- the same values as convert / subtract / convert, in
 // 1.5 instead of 2.5 VALU instructions per element (VALU time adds to the matrix time on a SIMD: profiles/r02_probes.log)
@@ -206,6 +212,8 @@ __device__ __forceinline__ void store_group_block(unsigned char* blk0, const flo
   __builtin_amdgcn_raw_buffer_store_b128(h1, rs, (int)off + 512, 0, FD_STORE_AUX);
   __builtin_amdgcn_raw_buffer_store_b128(l0, rs, (int)off + 2048, 0, FD_STORE_AUX);
   __builtin_amdgcn_raw_buffer_store_b128(l1, rs, (int)off + 2560, 0, FD_STORE_AUX);
+  store_guard(h0, h1);
+  store_guard(l0, l1);
 }
 __device__ __forceinline__ void load_group_block_raw(const unsigned char* blk0, u32x4 (&raw)[4], int l31, int half) {
   const unsigned off = (unsigned)(l31 * 16 + half * 1024);

@@ -113,6 +113,17 @@ def main(name):
         n += 1
         run(n)
     report("v", qkv("v"), cap["v"], False)
+    if os.environ.get("DEBUG_V"):  # where is v wrong: per sequence x head, and the positions of one bad (sequence, head)
+        dv = np.abs(qkv("v") - cap["v"].numpy()).reshape(B, L, H, 32)
+        bad = dv > 1e-4
+        print("    bad fraction per (sequence, head):")
+        for b in range(B):
+            print("     ", b, " ".join(f"{bad[b, :, hh].mean():.2f}" for hh in range(H)))
+        bb, hh = np.unravel_index(np.argmax(bad.mean(axis=(1, 3))), (B, H))
+        if bad.any():
+            print(f"    sequence {bb} head {hh}: bad positions", np.nonzero(bad[bb, :, hh].any(axis=1))[0].tolist()[:64])
+            print(f"    sequence {bb} head {hh}: bad d at the first bad position",
+                  np.nonzero(bad[bb, np.nonzero(bad[bb, :, hh].any(axis=1))[0][0], hh])[0].tolist())
     run(n + 1); report("ctx", rows_img("ctx", d), cap["ctx"], False)
     run(n + 2); report("a", rows_img("a", d), cap["a"], False)
     run(n + 3); report("g", rows_img("g", ff), cap["g"], False)
