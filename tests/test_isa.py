@@ -87,3 +87,54 @@ def test_k_loops_hold_no_scratch_and_no_vector_memory_wait(gemm_asm):
             waits = [b.strip() for b in body if re.search(r"s_waitcnt vmcnt\(\d+\)", b)]
             assert len(waits) == 0, (EPI[epi], waits)   # (round 2 tolerated one in the q|k / v^T kernels: the row info now lands in LDS)
         assert loops >= 1, EPI[epi]
+
+
+def _vgprs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def wide_store_hazards(asm):
+    """12- / 16-byte stores whose NEXT instruction is a VALU write of one of their data registers.
+
+    Round 3 met this once (profiles/r03_gemm_notes.log): `v_xor_b32 v82, 64, v121` right behind
+    `buffer_store_dwordx4 v[82:85], v121, s[16:19], s28 offen` stored wrong dwords on gfx950 -- hipcc pads the
+    hazard only for stores without an SGPR offset.  The product code now computes addresses before its store
+    groups and ends them with store_guard(); this is the net under it."""
+    lines = [ln.strip() for ln in asm.splitlines()]
+    lines = [ln for ln in lines if ln and not ln.startswith((";", ".", "//")) and not ln.endswith(":")]
+    found = []
+    for i, ln in enumerate(lines[:-1]):
+        m = re.match(r"(buffer|global|flat|scratch)_store_dwordx[34]\s+(.*)", ln)
+        if not m:
+            continue
+        ops = [o.strip() for o in m.group(2).split(",")]
+        data = _vgprs(ops[0]) if m.group(1) == "buffer" else _vgprs(ops[1]) if len(ops) > 1 else set()
+        nxt = re.match(r"(v_\w+)\s+([^,\s]+)", lines[i + 1])
+        if nxt and not nxt.group(1).startswith("v_cmp") and (_vgprs(nxt.group(2)) & data):
+            found.append((ln, lines[i + 1]))
+    return found
+
+
+def test_the_hazard_scanner_sees_the_pattern_it_is_for():
+    bad = "buffer_store_dwordx4 v[82:85], v121, s[16:19], s28 offen\n\tv_xor_b32_e32 v82, 64, v121\n"
+    good = "buffer_store_dwordx4 v[82:85], v121, s[16:19], s28 offen\n\ts_nop 0\n\tv_xor_b32_e32 v82, 64, v121\n"
+    assert len(wide_store_hazards(bad)) == 1 and not wide_store_hazards(good)
+
+
+@pytest.mark.parametrize("source", ["gemm_img", "rowwise_img", "attention_img"])
+def test_no_wide_store_is_followed_by_a_write_of_its_data_registers(source, tmp_path):
+    flags = fbuild.PER_SOURCE_FLAGS.get(source, [])  # the flags the product build uses for this source
+    try:
+        hipcc = fbuild.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    out = tmp_path / f"{source}.s"
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include")] + flags + [
+        "-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, f"{source}.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert wide_store_hazards(out.read_text()) == []
