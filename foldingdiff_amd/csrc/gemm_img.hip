@@ -52,6 +52,10 @@ template <int V> using IC = std::integral_constant<int, V>;
 #ifndef FDMI_LN_RD
 #define FDMI_LN_RD 1  // LayerNorm epilogue: residual half-blocks requested ahead
 #endif
+#ifndef FDMI_GEMM_NOBAR
+#define FDMI_GEMM_NOBAR 0  // ablation build (WRONG results): no workgroup barrier in the k-loop -- what would a barrier-free hand-off gain?
+#endif
+#define FD_KBAR() do { if (!FDMI_GEMM_NOBAR) barrier_keep_vm(); } while (0)
 #ifndef FDMI_G6FIRST
 #define FDMI_G6FIRST 1  // the wm 1 waves run MFMA group 6 before their first-fragment reads (0: every wave reads first); -0.6 % per timestep
 #endif
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     // g + 1 behind it), so the two barriers of a LayerNorm epilogue follow the barrier of the next tile's first position.
     for (int g = 0, kt = 0; g < G; ++g) {
       FD_WAIT_VM(16 / NL);
-      barrier_keep_vm();
+      FD_KBAR();
       issue_w();
       issue_a();
       if constexpr (EPI == EPI_IMG_LN) {
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #if FDMI_G6FIRST
       FD_WAIT_LGKM0();  // (the same wait as inside the barrier, but visible to the compiler's counter model: no waits in group 6)
 #endif
-      barrier_keep_vm();  // every fragment of this position is in registers: its slots are free; the next position landed
+      FD_KBAR();  // every fragment of this position is in registers: its slots are free; the next position landed
       FD_STAMP(2);
 #if FDMI_G6FIRST
       // Behind the barrier all eight waves want the LDS for their first fragments at once (~300 cycles during which no
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     groups_1_to_5(SW);
     FD_STAMP(1);
     const bool stream_end = ti + 1 == cnt;
-    if (!stream_end) barrier_keep_vm();
+    if (!stream_end) FD_KBAR();
     FD_STAMP(2);
     FD_STAMP(3);
     mm6(SW, Xb, Yb);  // 6: wl1 ah1
