@@ -128,7 +128,10 @@ int fd_set_option(fd_model* m, const char* name, int value);
 
 /* eps = model(x, t, attention_mask(lens)) -- BertForDiffusionBase.forward in eval
  * mode (modelling.py:384-484).  Host buffers.  t is constant over the batch, as
- * p_sample asserts (sampling.py:46-47). */
+ * p_sample asserts (sampling.py:46-47).
+ * Size limit of one call (every entry point that takes B and L): in the default precision the q / k / v images of the batch
+ * are addressed with 32-bit offsets, so B * n_heads * ceil(L / 32) * 4096 bytes must stay below 4 GiB (B < 21,845 sequences of
+ * L = 128 at 12 heads) -- FD_E_UNSUPPORTED beyond; sampling.sample chunks by batch_size long before that. */
 int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, float* eps_out);
 
 /* One reverse step: x_out = p_sample(x, t) (sampling.py:27-75); with wrap != 0 the
