@@ -7,6 +7,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== rocminfo"; /opt/rocm/bin/rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -6
 nproc; lscpu | grep "Model name"
+# which class of box is this (the pool has two: DESIGN.md section 4)?  clocks / power / temperature before and after the bench
+smi() { /opt/rocm/bin/rocm-smi --showtemp --showclocks --showpower 2>/dev/null | grep -E "junction|memory\)|sclk|mclk|fclk|Power \(W\)" | sed "s/^/[smi $1] /"; }
+smi start | tee $OUT/smi.log
 echo "== build"; python -m foldingdiff_amd.build 2>&1 | tail -2
 echo "== pytest -m gpu"
 timeout 1200 python -m pytest tests -q -m gpu --durations=8 -p no:cacheprovider 2>&1 | tail -60 | tee $OUT/pytest_gpu.log
@@ -14,6 +17,7 @@ echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.log
 echo "== bench"
 timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 ${BENCH_ARGS:-} 2>&1 | tail -3 | tee $OUT/bench.log
+smi after-bench | tee -a $OUT/smi.log
 if [ -n "${BENCH2_ARGS:-}" ]; then
   env ${BENCH2_ENV:-X=1} timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-exact-f32 $BENCH2_ARGS 2>&1 | tail -1 | tee $OUT/bench2.log
 fi
