@@ -352,3 +352,22 @@ def test_f16x3_split_arithmetic_is_fp32_class():
         back = (hi.astype(f64) + lo.astype(f64)) / f64(sa)
         big = np.abs(a) > np.abs(a).max() * 2.0 ** -10
         assert (np.abs(back - a)[big] / np.abs(a)[big]).max() <= 2.0 ** -22
+
+
+def test_vt_swizzle_is_conflict_free_for_16_lane_groups():
+    """The V^T rows' unit swizzle (img_common.h: vt_swz) against the LDS model the counters support: a ds_read_b64 is served in
+    16-lane groups against 32 banks, lane l31 reads the 8-byte unit (ua ^ vt_swz(l31)) of its own 128-byte row, so the 16 rows
+    of a group must name 16 different units.  The round-2 swizzle ((d >> 1) & 15) names only 8 (SQ_LDS_BANK_CONFLICT: one
+    extra cycle per group, profiles/r03_attention_notes.log)."""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "img_common.h")).read()
+    m = re.search(r"#else\s*\n__device__ __forceinline__ constexpr int vt_swz\(int d\) \{ return (.*?); \}", src)
+    assert m, "vt_swz not found"
+    swz = eval("lambda d: " + m.group(1))  # noqa: S307 -- an integer expression of d from our own header
+    old = lambda d: (d >> 1) & 15  # noqa: E731
+    for ua in range(16):
+        for g in range(2):
+            lanes = range(16 * g, 16 * g + 16)
+            assert len({ua ^ swz(d) for d in lanes}) == 16
+            assert len({ua ^ old(d) for d in lanes}) == 8
+    assert sorted(swz(d) for d in range(16)) == list(range(16))
