@@ -76,7 +76,7 @@ __device__ __forceinline__ void swap32(unsigned& vdst, unsigned& src) {
 // The attention kernel fetches its P V operand with ds_read_b64, lane = d: the LDS serves such a read in groups of 16 lanes
 // against 32 banks (128 bytes), so the 16 rows of a group must hit 16 different 8-byte slots.  ((d >> 1) & 15, chosen for
 // 32-lane groups over 64 banks, cost one extra LDS cycle per group: SQ_LDS_BANK_CONFLICT 3.1 M per launch = 5.4 % of the
-// kernel's cycles, profiles/r03_sq_counters.txt, r03_attention_notes.log.)
+// kernel's cycles, profiles/r03_sq_counters_before_vt_swizzle.txt, r03_attention_notes.log.)
 #ifdef FDMI_VT_SWZ_OLD  // A/B build: the round-2 swizzle
 __device__ __forceinline__ constexpr int vt_swz(int d) { return (d >> 1) & 15; }
 #else
