@@ -19,7 +19,8 @@ The JSON line also carries
   roofline      the dominant kernel (QKV-projection GEMM): algorithmic FLOPs per launch /
                 average launch duration measured live with hipEvents inside the timed
                 region (every 100th timestep is launched eagerly with an event pair per
-                kernel instead of replaying the graph), against the dense fp32-MFMA peak.
+                kernel instead of replaying the graph), against the dense MFMA peak of the instruction
+                actually used (fp16: 2500 TFLOP/s in the default f16x3 mode, fp32: 157.3 in --precision f32).
   cpu_baseline  the reference CPU path (oracle restatement, "port") timed on this box's
                 host cores over a bounded sample of the same workload.
   extras.c5     one pass of BASELINE config C5 (L = 512, batch 128, max_position_embeddings = 512).
@@ -111,6 +112,10 @@ def cpu_baseline(B, L, T, shape, steps=10, check_batch=8):
                   f"oracle: one step per candidate thread count of {cand} until past the knee ({', '.join(f'{c}: {v:.1f} s' for c, v in probe.items())}), "
                   f"the other {rest} at the best ({cores} threads): {per_step * 1e3:.0f} ms/step, extrapolated x{T}; "
                   f"{ncpu} logical CPUs",
+        # the same host at the batch size it runs most efficiently (the full batch thrashes on 403 MB of scores per layer):
+        # a complete T-step run, nothing extrapolated
+        "best_batch": {"batch": check_batch, "value": check_batch / full_dt, "unit": "backbones/s", "seconds": full_dt,
+                       "sample": f"complete T={T} run at batch {check_batch}, L={L}, {cores} threads"},
         "linearity_check": {"batch": check_batch, "full_T_seconds": full_dt, "first_K_steps_seconds": k_dt,
                             "extrapolated_seconds": k_dt * T / steps, "ratio_full_over_extrapolated": full_dt / (k_dt * T / steps),
                             "backbones_per_s": check_batch / full_dt},

@@ -78,19 +78,34 @@ def main(argv=None) -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     outdir = Path(args.outdir)
-    # every check that can fail is made BEFORE the process group exists: a rank that raises behind init_process_group leaves the
-    # others blocked in the first collective until the RCCL timeout
-    assert os.path.isdir(args.model), f"{args.model} is not a local model directory (there is no network access here)"
-    if rank == 0:
-        os.makedirs(outdir, exist_ok=True)
-        # Be extra cautious so we don't overwrite any results (bin/sample.py:299)
-        assert not os.listdir(outdir), f"Expected {outdir} to be empty!"
+    # EVERY rank evaluates the same preconditions, before anything is created and before the process group exists; the verdicts
+    # are then all-reduced so that either all ranks raise or none does (a rank that exits alone leaves the others blocked in
+    # init_process_group / the first collective until the rendezvous or RCCL timeout)
+    problem = ""
+    if not os.path.isdir(args.model):
+        problem = f"{args.model} is not a local model directory (there is no network access here)"
+    elif os.path.isdir(outdir) and os.listdir(outdir):
+        problem = f"Expected {outdir} to be empty!"  # Be extra cautious so we don't overwrite any results (bin/sample.py:299)
     if world > 1:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         args.device = f"cuda:{local_rank}"
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(args.device))
+        from foldingdiff_amd import distributed as fdist
+        if fdist.any_rank_failed(bool(problem), device=torch.device(args.device)):
+            dist.destroy_process_group()
+            raise AssertionError(problem or "another rank failed its start-up checks (see its log)")
+        if sampling.NOISE_MODE == "torch":
+            # the reference's draw order needs every rank to draw the WHOLE batch's stream on one host thread: it reproduces the
+            # single-process samples bit for bit, but it does not scale (12.6 GB of torch.randn per rank per batch of 4096 x 128)
+            logging.warning("world size %d with the default noise mode 'torch': every rank draws the whole batch's noise on the host "
+                            "(bit-identical to a single-process run, but it will not scale); set FOLDINGDIFF_AMD_NOISE=philox "
+                            "for on-device noise keyed by the global sequence index", world)
+    elif problem:
+        raise AssertionError(problem)
+    if rank == 0:
+        os.makedirs(outdir, exist_ok=True)
 
     train_dset = build_datasets(Path(args.model))
     model = modelling.BertForDiffusionBase.from_dir(

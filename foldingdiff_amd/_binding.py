@@ -17,7 +17,7 @@ FD_DEC = {"mlp": 0, "linear": 1}
 FD_PREC_F32 = 0
 FD_PREC_F16X3 = 1
 FD_PREC = {"f32": 0, "f16x3": 1}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FdmiError(RuntimeError):
@@ -92,13 +92,17 @@ def load() -> C.CDLL:
             "Run `python -m foldingdiff_amd.build` (needs hipcc). There is no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError => ABI mismatch, surface it
-        fn.restype = res
-        fn.argtypes = args
+    # the version first: an older library then fails with a version message, not with a missing-symbol AttributeError
+    lib.fd_abi_version.restype = C.c_int
+    lib.fd_abi_version.argtypes = []
     v = lib.fd_abi_version()
     if v != ABI_VERSION:
-        raise RuntimeError(f"libfdmi ABI version {v}, binding expects {ABI_VERSION}; rebuild")
+        raise RuntimeError(f"{LIB_PATH}: libfdmi ABI version {v}, this binding expects {ABI_VERSION}; "
+                           "rebuild with `python -m foldingdiff_amd.build --force`")
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => header / library mismatch, surface it
+        fn.restype = res
+        fn.argtypes = args
     _lib = lib
     return lib
 

@@ -140,6 +140,8 @@ struct fd_model {
   int comm_world = 0, comm_rank = 0;
   UpdateDyn dyn_host{};  // per-run values of the sampling loop in progress (fd_sample_begin_dev .. fd_sample_end_dev)
   int run_t = -1;        // next timestep of that run (-1: none left)
+  bool run_open = false; // between fd_sample_begin_dev and fd_sample_end_dev, with no other call on the model in between
+  int run_B = 0, run_L = 0;  // its shape: fd_sample_steps_dev / _end_dev refuse to run on another workspace
   // profiling
   int profile_every = 0;
   double prof_ms[KC_COUNT] = {0};
@@ -324,8 +326,14 @@ void drop_workspaces(fd_model* m) {
   m->cache.clear();
 }
 
+size_t kHeadBytes(const fd_config& c) { return (size_t)(c.d_model / c.n_heads) * 4; }  // q / k / v image bytes per position and head
+
 int ensure_ws(fd_model* m, int B, int L) {
   Workspace& w = m->ws;
+  // every entry point that takes a workspace comes through here: a sampling run begun earlier (fd_sample_begin_dev) is over --
+  // its state (x, the step counter) is about to be overwritten or parked; fd_sample_begin_dev re-opens one afterwards
+  m->run_t = -1;
+  m->run_open = false;
   const fd_config& c = m->cfg;
   const size_t M = (size_t)B * L, d = c.d_model, F = c.n_features;
   // algorithmic work per launch: 2*M*N*K for GEMMs, 6*L*d per token for attention
@@ -372,6 +380,14 @@ int ensure_ws(fd_model* m, int B, int L) {
     m->cache[old].release();
     m->cache.erase(m->cache.begin() + old);
   }
+  if (m->img) {  // every shape check comes BEFORE the first allocation: an early return must not leave buffers behind
+    const int Tt = L > 128 ? 4 : (L + 31) / 32;
+    const size_t ltot = (size_t)(L > 128 ? (L + 127) / 128 : 1) * 32 * Tt;
+    if ((size_t)B * c.n_heads * ltot * kHeadBytes(c) >= (1ull << 32))
+      return fail(FD_E_UNSUPPORTED, "B=%lld x heads x L=%d: the q / k / v images of one batch must stay below 4 GiB; use smaller batches",
+                  (long long)B, (int)L);
+  }
+  const int rc_alloc = [&]() -> int {
   auto al = [&](void** p, size_t bytes) -> hipError_t { return hipMalloc(p, bytes); };
   auto alz = [&](void** p, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(p, bytes);
@@ -399,9 +415,6 @@ int ensure_ws(fd_model* m, int B, int L) {
     HIP_TRY(alz((void**)&w.cimg, cap * d * 4));
     HIP_TRY(alz((void**)&w.gimg, cap * gmax * 4));
     if (d > 384) HIP_TRY(alz((void**)&w.tmp, cap * d * 4));  // pre-LayerNorm fp32 rows (un-fused LayerNorm path)
-    if (BH * w.LTOT * 128 >= (1ull << 32))
-      return fail(FD_E_UNSUPPORTED, "B=%lld x heads x L=%d: the q / k / v images of one batch must stay below 4 GiB; use smaller batches",
-                  (long long)B, (int)L);
     HIP_TRY(alz((void**)&w.qbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.kbuf, BH * w.LTOT * 128));
     HIP_TRY(alz((void**)&w.vbuf, BH * w.LTOT * 128));
@@ -424,6 +437,13 @@ int ensure_ws(fd_model* m, int B, int L) {
     HIP_TRY(alz((void**)&w.a, Mp * d * 4));
     HIP_TRY(al((void**)&w.tmp, M * d * 4));
     HIP_TRY(alz((void**)&w.g, Mp * gmax * 4));
+  }
+    return FD_OK;
+  }();
+  if (rc_alloc) {  // (out of memory, ...): give back what was allocated; w.B stays 0
+    (void)hipStreamSynchronize(m->stream);
+    w.release();
+    return rc_alloc;
   }
   w.B = B;
   w.L = L;
@@ -1308,12 +1328,18 @@ int fd_sample_begin_dev(fd_model* m, const void* x_init_dev, const void* lens_de
   dyn.t_start = t_start;
   dyn.hist_every = full_history;
   m->run_t = t_start;
+  m->run_open = true;
+  m->run_B = B;
+  m->run_L = L;
   if (int rc = set_t(m, s, t_start)) return rc;
   return FD_OK;
 }
 
 int fd_sample_steps_dev(fd_model* m, int n_steps, const void* noise_dev, int noise_t0, void* hip_stream) {
   if (!m || !m->finalized || m->ws.B == 0) return fail(FD_E_STATE, "fd_sample_steps_dev without fd_sample_begin_dev");
+  if (!m->run_open) return fail(FD_E_STATE, "fd_sample_steps_dev: no sampling run in progress (another call on this model has taken its workspace)");
+  if (m->ws.B != m->run_B || m->ws.L != m->run_L)
+    return fail(FD_E_STATE, "fd_sample_steps_dev: the workspace now holds B=%d L=%d, the run was begun with B=%d L=%d", m->ws.B, m->ws.L, m->run_B, m->run_L);
   if (n_steps < 0 || n_steps > m->run_t + 1) return fail(FD_E_INVALID, "n_steps = %d with %d steps left", n_steps, m->run_t + 1);
   if (noise_dev && (noise_t0 < 0 || noise_t0 > m->run_t - n_steps + 1))  // (the row of t = 0 is read too, and multiplied by sigma_0 = 0)
     return fail(FD_E_INVALID, "noise rows start at t = %d, the steps run down to t = %d", noise_t0, m->run_t - n_steps + 1);
@@ -1344,11 +1370,16 @@ int fd_sample_steps_dev(fd_model* m, int n_steps, const void* noise_dev, int noi
 
 int fd_sample_end_dev(fd_model* m, void* out_dev, void* hip_stream) {
   if (!m || !m->finalized || m->ws.B == 0) return fail(FD_E_STATE, "fd_sample_end_dev without fd_sample_begin_dev");
+  if (!m->run_open) return fail(FD_E_STATE, "fd_sample_end_dev: no sampling run in progress (another call on this model has taken its workspace)");
   if (m->run_t >= 0) return fail(FD_E_STATE, "%d reverse steps have not been run", m->run_t + 1);
+  if (m->ws.B != m->run_B || m->ws.L != m->run_L)
+    return fail(FD_E_STATE, "fd_sample_end_dev: the workspace now holds B=%d L=%d, the run was begun with B=%d L=%d", m->ws.B, m->ws.L, m->run_B, m->run_L);
+  HIP_TRY(hipSetDevice(m->device));
   Workspace& w = m->ws;
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
   const size_t n = (size_t)w.B * w.L * m->cfg.n_features;
   if (!m->dyn_host.hist_every) HIP_TRY(hipMemcpyAsync(out_dev, w.x, n * 4, hipMemcpyDeviceToDevice, s));
+  m->run_open = false;
   return FD_OK;
 }
 

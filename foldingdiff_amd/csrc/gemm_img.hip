@@ -29,11 +29,13 @@
 //  * "swapped" MFMA form (D^T = W A^T; everything but the v tiles): a lane owns ONE token row and 16 columns, so LayerNorm
 //    statistics are in-lane sums, and a block is written with four 16-byte stores per lane after a half-wave register
 //    exchange (img_common.h); the grouped image layout makes each of those stores 512 contiguous bytes per half-wave.
-//  What bounds it (profiles/r02_gemm_ablation.log, r02_probes.log): MFMA and VALU instructions of different waves do NOT
-//  overlap on a SIMD (co-issue probe), so epilogue arithmetic adds to the matrix time; the k-loop runs at ~2900 cycles per
-//  k-tile for 2304 matrix cycles; and the outputs' HBM writes cost ~1.8 ms of a 7.7 ms timestep.  That last cost is the
-//  traffic itself, not a chip-wide store burst: with the workgroups' start times spread over a tile period a tile costs the
-//  same (de-phase probe, third part of the ablation log).
+//  What bounds it (profiles/r02_gemm_ablation.log, r02_probes.log, r03_coissue2_probe.log, r03_pingpong_*.log): the k-loop runs
+//  at ~2900 cycles per k-tile for 2304 matrix cycles -- the loader stream alone (64 KiB per k-tile through the CU's L2 -> LDS
+//  path) needs 2200-2900; the tile epilogues run with the matrix pipe idle because BOTH waves of a SIMD are in the epilogue
+//  together (plain fp32 VALU of one wave does issue beside another wave's MFMAs; only PACKED fp32 serializes with the matrix
+//  pipe); and the outputs' HBM writes cost ~1.8 ms of a 7.7 ms timestep.  That last cost is the traffic itself, not a
+//  chip-wide store burst: with the workgroups' start times spread over a tile period a tile costs the same (de-phase probe,
+//  third part of the r02 ablation log).
 #include <cstdlib>
 #include <type_traits>
 

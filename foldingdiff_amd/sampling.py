@@ -170,32 +170,43 @@ def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start:
 
     th = threading.Thread(target=draw, args=(0,))
     th.start()
-    _binding.check(lib.fd_sample_begin_dev(h, C.c_void_p(x_d.data_ptr()), C.c_void_p(lens_d.data_ptr()), B, L, t_start,
-                                           C.c_uint64(0), C.c_int64(seq_offset), C.c_void_p(out_d.data_ptr()), full_history,
-                                           C.c_void_p(run_s.cuda_stream)))
-    for k, (t_lo, t_hi) in enumerate(chunks):
-        th.join()
-        if err:
-            raise err[0]
-        b = k % 2
-        with torch.cuda.stream(copy_s):
-            if consumed[b] is not None:
-                copy_s.wait_event(consumed[b])          # the device is done with this buffer's previous content
-            dbuf[b][: t_hi - t_lo + 1].copy_(pinned[b][: t_hi - t_lo + 1], non_blocking=True)
-            copied[b].record(copy_s)
-        if k + 1 < len(chunks):
-            if k >= 1:
-                copied[(k + 1) % 2].synchronize()       # its upload has left the pinned buffer the thread writes next
-            th = threading.Thread(target=draw, args=(k + 1,))
-            th.start()
-        run_s.wait_event(copied[b])
-        _binding.check(lib.fd_sample_steps_dev(h, t_hi - t_lo + 1, C.c_void_p(dbuf[b].data_ptr()), t_lo,
+    try:
+        _binding.check(lib.fd_sample_begin_dev(h, C.c_void_p(x_d.data_ptr()), C.c_void_p(lens_d.data_ptr()), B, L, t_start,
+                                               C.c_uint64(0), C.c_int64(seq_offset), C.c_void_p(out_d.data_ptr()), full_history,
                                                C.c_void_p(run_s.cuda_stream)))
-        consumed[b] = torch.cuda.Event()
-        consumed[b].record(run_s)
-    _binding.check(lib.fd_sample_end_dev(h, C.c_void_p(out_d.data_ptr()), C.c_void_p(run_s.cuda_stream)))
-    run_s.synchronize()
-    _binding.check(lib.fd_check_finite(h))
+        for k, (t_lo, t_hi) in enumerate(chunks):
+            th.join()
+            if err:
+                raise err[0]
+            b = k % 2
+            with torch.cuda.stream(copy_s):
+                if consumed[b] is not None:
+                    copy_s.wait_event(consumed[b])          # the device is done with this buffer's previous content
+                dbuf[b][: t_hi - t_lo + 1].copy_(pinned[b][: t_hi - t_lo + 1], non_blocking=True)
+                copied[b].record(copy_s)
+            if k + 1 < len(chunks):
+                if k >= 1:
+                    copied[(k + 1) % 2].synchronize()       # its upload has left the pinned buffer the thread writes next
+                th = threading.Thread(target=draw, args=(k + 1,))
+                th.start()
+            run_s.wait_event(copied[b])
+            _binding.check(lib.fd_sample_steps_dev(h, t_hi - t_lo + 1, C.c_void_p(dbuf[b].data_ptr()), t_lo,
+                                                   C.c_void_p(run_s.cuda_stream)))
+            consumed[b] = torch.cuda.Event()
+            consumed[b].record(run_s)
+        _binding.check(lib.fd_sample_end_dev(h, C.c_void_p(out_d.data_ptr()), C.c_void_p(run_s.cuda_stream)))
+        run_s.synchronize()
+        _binding.check(lib.fd_check_finite(h))
+    except BaseException:
+        # a failed call must not leave the draw thread consuming torch's global generator into a cached pinned buffer, nor
+        # x_d / lens_d / out_d go back to the allocator under streams that still use them; the buffers of this
+        # shape are dropped, the next call starts from fresh ones
+        _NOISE_BUFFERS.pop(key, None)
+        raise
+    finally:
+        th.join()
+        run_s.synchronize()
+        copy_s.synchronize()
     out[:] = out_d.cpu().numpy()
 
 

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define FDMI_ABI_VERSION 1
+/* 2: fd_sample_steps_dev / fd_sample_end_dev return FD_E_STATE when another call has taken the run's workspace; history
+ *    padding of packed rows is zeroed; head sizes other than 32 (multiples of 32) are accepted */
+#define FDMI_ABI_VERSION 2
 
 enum {
   FD_OK = 0,
