@@ -383,7 +383,7 @@ int ensure_ws(fd_model* m, int B, int L) {
   if (m->img) {  // every shape check comes BEFORE the first allocation: an early return must not leave buffers behind
     const int Tt = L > 128 ? 4 : (L + 31) / 32;
     const size_t ltot = (size_t)(L > 128 ? (L + 127) / 128 : 1) * 32 * Tt;
-    if ((size_t)B * c.n_heads * ltot * kHeadBytes(c) >= (1ull << 32))
+    if ((size_t)B * c.n_heads * ltot * kHeadBytes(c) >= (1ull << 32) - 65536)  // (32-bit offsets, the top bytes mark dropped stores)
       return fail(FD_E_UNSUPPORTED, "B=%lld x heads x L=%d: the q / k / v images of one batch must stay below 4 GiB; use smaller batches",
                   (long long)B, (int)L);
   }

@@ -20,7 +20,9 @@
 // so every copy has a whole compute phase to land.  Waits are counted (s_waitcnt vmcnt(N)), never 0 in the loop.
 // A wave owns one 32-query row block; S^T (keys x queries) puts a query's scores in one lane pair, so softmax is
 // in-register and P is already the B operand of the PV MFMA; the relative_key term is dense 32x32 tiles
-// R = Q E^T over the band, skewed through a per-wave LDS scratch (see the comments inside).
+// R^T = E Q^T over the band (rows = band, columns = queries), skewed through a per-wave LDS scratch of TWO tiles in which
+// the band rows of a tile pair are consecutive 128-byte rows: a score's band value sits at an address LINEAR in its key,
+// so the gather is one ds_read_b32 with an immediate offset and one fma per score (see the comments inside).
 // ctx leaves as a grouped row image (img_common.h) with one 128-byte block per (token row, head) for the attention-output GEMM.
 #include <cstdlib>
 
@@ -38,12 +40,37 @@ namespace ai {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
+// 32-bit LDS addresses kept in registers across the item loop (a generic pointer would pin a register PAIR each)
+typedef const __attribute__((address_space(3))) float* lds_cf32_t;
+typedef const __attribute__((address_space(3))) u32x4* lds_cu128_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(lds_ptr_t)(const_cast<void*>(p)); }
+__device__ __forceinline__ float lds_f32(unsigned a) { return *(lds_cf32_t)(unsigned long long)a; }
+__device__ __forceinline__ u32x4 lds_u128(unsigned a) { return *(lds_cu128_t)(unsigned long long)a; }
+
 
 constexpr float PS = 1024.0f;  // probabilities are <= 1
 constexpr float kLog2e = 1.44269504088896341f;
 constexpr float kInvSqrtD = 0.17677669529663687f;  // 1 / sqrt(32)
 
 __device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
+// reductions over a lane pair (lane, lane ^ 32): one v_permlane32_swap leaves [x lo | x lo] and [x hi | x hi], and the symmetric
+// operation gives BOTH halves the same bits (__shfl_xor is a ds_bpermute: six address instructions and an LDS round trip)
+__device__ __forceinline__ void pair_halves(float x, float& lo, float& hi) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  swap32(a, b);  // lanes 32-63 of a <-> lanes 0-31 of b
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float pair_max(float x) {
+  float lo, hi;
+  pair_halves(x, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  float lo, hi;
+  pair_halves(x, lo, hi);
+  return lo + hi;
+}
 
 constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -55,8 +82,42 @@ struct Geo {
   static constexpr int KW = ceil_div(KC, 4), VW = ceil_div(VC, 4);  // DMA pieces per wave (4 waves per group)
   static constexpr int E_BYTES = ELDS ? 32 * 1024 : 0;              // distance table image, 255 rows x 128 B (maxpos <= 128)
   static constexpr int OFF_K = 0, OFF_V = OFF_K + KW * 4 * 1024, OFF_R = OFF_V + VW * 4 * 1024;
-  static constexpr int G_REL = OFF_R + 4 * 32 * 32 * 4, G_ABS = OFF_R;  // bytes per group (skew scratch: 4 KiB per wave)
+  static constexpr int G_REL = OFF_R + 4 * 2 * 32 * 32 * 4, G_ABS = OFF_R;  // bytes per group (skew scratch: two 4 KiB tile slots per wave)
 };
+
+// compile-time loop
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(IC<LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
+// The relative_key band of a position as a sequence of operations on band tiles q = 0 .. T (32 band rows each):
+//     M(q)  R^T tile q = E_tile Q^T, six MFMAs into accumulator q & 1
+//     W(q)  accumulator q & 1 -> scratch slot q & 1 (16 ds_write_addtid_b32)
+//     G(q)  S^T tile T-1-q += the band values of the tile PAIR (q, q+1): 16 gathers + 16 fmas
+// software pipelined so that the MFMAs of tile q+2 are issued BEFORE the gathers of pair q (they run under the gather's LDS round
+// trip and fmas; round 3 ran MFMA -> write -> read -> fma of one tile strictly in sequence):
+//     M0 M1 W0 W1 M2 | G0 W2 M3 | G1 W3 M4 | G2 W4 | G3          (T = 4; operations on tiles beyond T do not exist)
+// W(q+2) follows G(q) in program order: it overwrites the slot pair q read (LDS operations of one wave execute in order).
+struct BandOp {
+  int kind, q;  // 0 M, 1 W, 2 G, -1 nothing
+};
+template <int T>
+constexpr BandOp band_op(int i) {
+  BandOp o{-1, 0};
+  if (i < 5) {
+    const int kinds[5] = {0, 0, 1, 1, 0}, qs[5] = {0, 1, 0, 1, 2};
+    o = BandOp{kinds[i], qs[i]};
+  } else {
+    const int k = i - 5, q = k / 3, w = k % 3;
+    o = w == 0 ? BandOp{2, q} : (w == 1 ? BandOp{1, q + 2} : BandOp{0, q + 3});
+  }
+  if (o.kind == 2 ? o.q > T - 1 : o.q > T) o.kind = -1;
+  return o;
+}
 
 // Two 4-wave groups per workgroup (8 waves, one workgroup per CU), each group walking its own stream of
 // (item, key tile) positions in lockstep with the other (shared barriers), both sharing ONE copy of the distance
@@ -68,27 +129,28 @@ struct Geo {
 // RKQ: position_embedding_type = "relative_key_query" (HF BertSelfAttention 4.11.3; offered by the reference's training CLI,
 // bin/train.py:305-307): the score also gets  k_r . E[l - r + maxpos - 1]  -- the same band of the distance table paired with
 // the KEYS.  Per S^T tile t that is two more dense 32 x 32 tiles K_t E^T (rows = keys, i.e. the S^T tile's own rows) against the
-// band tiles T-1-t and T-t, skewed through the same per-wave scratch: lane (query l31) register r (key kl) reads
+// band tiles T-1-t and T-t, skewed through a scratch slot while it is free: lane (query l31) register r (key kl) reads
 // scratch[r][half][(l31 - kl + 31) & 31] -- the scratch ROW is the register's own, only the column is skewed.
 template <int T, bool REL, bool ELDS, int NG, bool SAFE, bool PROF = false, bool RKQ = false>
 __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   static_assert(REL || !RKQ, "relative_key_query is a relative position type");
   // STAG: group 1 runs HALF A POSITION behind group 0.  A position is two halves of three barrier-separated segments each:
-  //     H1  [A] S^T tiles + band tiles [0, B1)  |  band tiles [B1, B2)  |  band tiles [B2, T]           (matrix heavy)
-  //     H2  [B] issue K(p+1), softmax           |  [C] P V              |  [D] issue V(p+1), ctx store  (VALU heavy)
+  //     H1  [A] S^T tiles + band operations [0, BP1)  |  band operations [BP1, BP2)  |  band operations [BP2, end)   (matrix heavy)
+  //     H2  [B] issue K(p+1), softmax                 |  [C] P V                    |  [D] issue V(p+1), ctx store  (VALU heavy)
   // so on every SIMD one wave is in H1 while the other is in H2: the plain fp32 VALU instructions of the one issue beside the
   // MFMAs of the other (profiles/r03_coissue2_probe.log; this file is compiled with -fno-slp-vectorize, packed fp32 would
   // serialize with the matrix pipe).  In lockstep both waves of a SIMD ran the same phase and the matrix pipe idled through
   // every softmax (29 % MFMA utilisation, cycle stamps).  Group 1 starts with an empty half, group 0 ends with one.
   constexpr bool STAG = FDMI_ATTN_STAG != 0 && NG == 2;
 #ifndef FDMI_ATTN_DBG
-#define FDMI_ATTN_DBG 0  // ablation builds (wrong results): linear LDS addresses for 1 the V reads, 2 the K reads, 4 the skew gather, 8 the table reads, 16 plain scratch stores
+#define FDMI_ATTN_DBG 0  // ablation builds (wrong results): linear LDS addresses for 1 the V reads, 2 the K reads; 32 no arithmetic (copies, barriers and stores only); 64 no copies / loads / stores in the item loop (arithmetic only)
 #endif
-#ifndef FDMI_ATTN_B1
-#define FDMI_ATTN_B1 1
-#define FDMI_ATTN_B2 3
+#ifndef FDMI_ATTN_BP1
+#define FDMI_ATTN_BP1 5   // band operations in front of the first / second barrier of H1 (see band_op); same-box, attention at C2:
+#define FDMI_ATTN_BP2 8   // (5, 8) 101.2 us, (4, 10) 104.8, (5, 11) 105.1, (7, 11) 107.5; round-3 kernel 106.1 (profiles/r04_attention_ab1.log)
 #endif
-  constexpr int B1 = T >= 3 ? FDMI_ATTN_B1 : 1, B2 = T >= 3 ? FDMI_ATTN_B2 : 2;  // band tile runs (T + 1 tiles)
+  constexpr int NOPS = REL ? 5 + 3 * T : 0;
+  constexpr int BP1 = FDMI_ATTN_BP1 < NOPS ? FDMI_ATTN_BP1 : NOPS, BP2 = FDMI_ATTN_BP2 < NOPS ? (FDMI_ATTN_BP2 > BP1 ? FDMI_ATTN_BP2 : BP1) : NOPS;
   using G = Geo<T, ELDS>;
   constexpr int LP = G::LP;
   constexpr int GSZ = REL ? G::G_REL : G::G_ABS;
@@ -101,11 +163,26 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   unsigned char* gbase = smem + G::E_BYTES + grp * GSZ;
   unsigned char* Ks = gbase + G::OFF_K;
   unsigned char* Vt = gbase + G::OFF_V;
-  float* Rw = reinterpret_cast<float*>(gbase + G::OFF_R) + wq * 32 * 32;
-  // this wave's skew scratch: LDS byte address for the addtid stores, and the row this lane reads back (query l31 =
-  // 8q + 4h + e lives at register slot 4q + e, half h)
-  const unsigned rw_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)(reinterpret_cast<unsigned char*>(Rw)));
-  const float* Rrow = Rw + ((l31 >> 3) * 4 + (l31 & 3)) * 64 + ((l31 >> 2) & 1) * 32;
+  // this wave's skew scratch: two 4 KiB slots, band tile q in slot q & 1, row (band index within the tile) x 128 B, column = query
+  unsigned char* Rw = gbase + G::OFF_R + wq * 8192;
+  const unsigned rw_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)(Rw));
+  // MFMA row i of a band tile computes band row pi(i) of the tile, pi(8a + 4h + e) = 8a + 2e + h: the C/D layout puts row
+  // 8a + 4h + e into register 4a + e of half-wave h, and ds_write_addtid_b32 of register r lands at (2r + h) * 128 + 4 * column --
+  // with the rows permuted like this the scratch row IS the band index.
+  const int pi31 = (l31 & 24) | ((l31 & 3) << 1) | ((l31 >> 2) & 1);
+  // gather base of this lane: query l31, key kl = kl_r + 4 half (register r: kl_r = (r & 3) + 8 (r >> 2)) needs band index
+  // j = l31 - kl + 31 of its tile pair, i.e. byte j * 128 + 4 l31 = gb + (27 - kl_r) * 128 when the pair's lower tile sits in slot 0
+  const unsigned gb = lds_addr(Rw) + (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31);
+  // ... and when it sits in slot 1 (odd pairs) the two slots are swapped: scores whose band index is >= 32 (l31 > kl) read 4096
+  // bytes lower, the others 4096 bytes higher.  One address register per score register, shared by every odd pair and computed
+  // once per kernel (opaque to the compiler, which otherwise keeps the sixteen +-4096 and adds gb to each at every use).
+  unsigned godd[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+    godd[r] = REL && T >= 2 ? (l31 > kl ? gb - 4096 : gb + 4096) : gb;
+    if (REL && T >= 2) asm volatile("" : "+v"(godd[r]));
+  }
   const int H = p.H, nqg = p.NKT;  // query groups == key tiles
   const int nitems = p.B * H * nqg;
   const int gstride = NG * gridDim.x;
@@ -168,39 +245,56 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     copy(p.vbuf + (bh * p.LTOT + (size_t)s.kt * LP) * 128, G::V_BYTES, G::VC, G::VW, Vt);
   };
   // Q operand of this lane: query l31 of the wave's row block, d = 16c + 8 half + j: units 2c + half (hi), 4 + 2c + half (lo)
-  auto load_q = [&](const Pos& s, u32x4 (&q)[4]) {
+  // It is fetched straight into the operand registers qh / ql when the NEXT position starts an item: that happens behind barrier
+  // [B] of an item's last position, and the S^T / band phase -- the only reader of qh / ql -- of that position is over by then.
+  f16x8 qh[2], ql[2];
+  auto load_q = [&](const Pos& s) {
     const size_t bh = (size_t)s.b * H + s.h;
     // the wave's 32 queries are one group of the grouped image: unit u of query l31 at (u * 32 + l31) * 16
     const u32x4* grp0 = reinterpret_cast<const u32x4*>(p.qbuf + (bh * p.LTOT + (size_t)s.qg * LP + 32 * (wq < T ? wq : 0)) * 128);
-    q[0] = grp0[half * 32 + l31]; q[1] = grp0[(2 + half) * 32 + l31]; q[2] = grp0[(4 + half) * 32 + l31]; q[3] = grp0[(6 + half) * 32 + l31];
+    qh[0] = __builtin_bit_cast(f16x8, grp0[half * 32 + l31]);
+    qh[1] = __builtin_bit_cast(f16x8, grp0[(2 + half) * 32 + l31]);
+    ql[0] = __builtin_bit_cast(f16x8, grp0[(4 + half) * 32 + l31]);
+    ql[1] = __builtin_bit_cast(f16x8, grp0[(6 + half) * 32 + l31]);
   };
 
-  // band weights of the relative_key skew (see the S phase): r_scale where register r of this lane belongs to the lower /
-  // upper S^T tile of a band tile's pair, else 0
-  float bw_lo[16], bw_hi[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-    bw_lo[r] = (REL && l31 <= kl) ? p.r_scale : 0.f;
-    bw_hi[r] = (REL && l31 > kl) ? p.r_scale : 0.f;
-  }
   Pos cur, nxt;
   load_item(cur, NG * blockIdx.x + grp);
-  u32x4 qn[4];
+  // ELDS: LDS row rho of the table copy holds table row clamp(rho - esh, 0, 2 maxpos - 2) for ALL 256 rows, esh = max(0, LP - maxpos):
+  // every band row a wave can ask for (rho = maxpos - LP + esh + 32 wq + 32 q + row, 0 <= rho <= 255) exists in LDS, so the
+  // fragment addresses need no clamp, are the same for every item, and tile q sits 4096 q bytes behind tile 0 (immediate offsets).
+  // Rows outside the table are only ever paired with padding keys / queries (L <= maxpos): any finite content will do.
+  const int esh = ELDS ? (LP > p.maxpos ? LP - p.maxpos : 0) : 0;
   if constexpr (REL && ELDS) {
-    // distance table -> LDS once per workgroup: 32 pieces of 8 rows, unit u of row m stored at u ^ ((m >> 1) & 7)
+    // distance table -> LDS once per workgroup: 32 pieces of 8 rows, unit u of LDS row rho stored at u ^ ((rho >> 1) & 7)
     const int nrow_e = 2 * p.maxpos - 1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.demb)), 0, nrow_e * 128, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 8 / NG; ++i) {
-      const int piece = wid + 4 * NG * i;  // rows 8 piece .. 8 piece + 7
-      const int row = 8 * piece + (lane >> 3);
-      dma16(rs, (lds_ptr_t)(Es) + piece * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4), 0);
+      const int piece = wid + 4 * NG * i;  // LDS rows 8 piece .. 8 piece + 7
+      const int rho = 8 * piece + (lane >> 3);
+      int row = rho - esh;
+      row = row < 0 ? 0 : (row > nrow_e - 1 ? nrow_e - 1 : row);
+      dma16(rs, (lds_ptr_t)(Es) + piece * 1024, row * 128 + (((lane & 7) ^ ((rho >> 1) & 7)) << 4), 0);
+    }
+  }
+  // ELDS: addresses of this lane's four operand units of band tile 0 (MFMA row l31 -> band row pi31; `eun`: un-permuted rows for the
+  // relative_key_query key term); tile q is at + 4096 q
+  unsigned eaddr[4] = {0, 0, 0, 0}, eun[4] = {0, 0, 0, 0};
+  if constexpr (REL && ELDS) {
+    const int rho0 = p.maxpos - LP + esh + 32 * wq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rp = rho0 + pi31, ru = rho0 + l31;
+      eaddr[k] = lds_addr(Es) + (unsigned)(rp * 128 + (((2 * k + half) ^ ((rp >> 1) & 7)) << 4));
+      eun[k] = lds_addr(Es) + (unsigned)(ru * 128 + (((2 * k + half) ^ ((ru >> 1) & 7)) << 4));
+      asm volatile("" : "+v"(eaddr[k]));
+      if (RKQ) asm volatile("" : "+v"(eun[k]));
     }
   }
   issue_k(cur);
-  load_q(cur, qn);
+  load_q(cur);
   issue_v(cur);
   nxt = cur;
   bool done = is_last(cur) || !has_work;
@@ -208,7 +302,6 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
 
   const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
   const float mask_raw = -10000.0f * kLog2e / s_scale;                  // (1 - mask) * -10000 at the raw scale
-  f16x8 qh[2], ql[2];
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc;
   bool stored_prev = false;  // the previous position ended an item (4 ctx stores are younger than its V copy)
@@ -216,6 +309,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   unsigned long long* st = PROF ? p.stamps + (size_t)wq * 64 * 8 : nullptr;
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define FD_SB() __builtin_amdgcn_sched_barrier(0)
 
   if constexpr (STAG) {
     if (grp == 1) {  // (its copies of the distance table must have landed before group 0 reads the table behind this barrier)
@@ -234,9 +328,16 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     const int Lb = p.nrow[b];                    // real rows: positions >= Lb are not keys at all
     const int l0 = qg * LP + 32 * wq;
     const bool active = live && wq < T && l0 < nrows;
+    const bool compute = active && !(FDMI_ATTN_DBG & 32);
     const int r0 = kt * LP;
     const bool first_tile = kt == 0;
     const bool nxt_first = nxt.kt == 0 && !done;  // the next position starts an item: its Q is fetched with its K
+    // 32-key tiles of this position that hold at least one key (packed rows: Lb = the sequence's length; keys beyond it are
+    // -inf scores = probability exactly 0): the S^T, band, softmax and P V work of the other tiles is skipped, bit-identically
+    // (they would add exact zeros).  Padded rows: Lb = L, every tile is live.
+    int tl = (Lb - r0 + 31) >> 5;
+    tl = tl < 1 ? 1 : (tl > T ? T : tl);
+    const int q0 = T - tl;  // first band tile any live S^T tile needs
 
     // ---- [A] K(p) (+ Q(p)) landed.  Younger: V(p) pieces, and the ctx stores of the previous position.
     if (SAFE) FD_WAIT_VM(0);
@@ -246,55 +347,59 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     barrier_keep_vm();
     FD_STAMP(2);
     if (first_tile) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        qh[c] = __builtin_bit_cast(f16x8, qn[c]);
-        ql[c] = __builtin_bit_cast(f16x8, qn[2 + c]);
-      }
       m_run = -INFINITY;
       l_run = 0.f;
+      if constexpr (!ELDS) {  // (ELDS: one key tile per item, the first P V product starts from the constant 0)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+      }
     }
 
     f32x16 sacc[T];
+    f32x16 racc[2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // ---- relative_key band (used inside the `active` blocks below)
-    // R tile q: rows = queries rowmap(r, half), cols = band index 32 q + l31 (band origin: this wave's row
-    // block).  S^T tile t element (key kl, query ql) needs band column j = ql - kl + 31 of the tile pair
-    // (q = T-1-t, q+1): j < 32 -> tile q, else tile q+1 column j-32.  Band row of R tile q, column l31:
-    //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + 32 q + l31, clamped: rows outside the table are only
-    // ever paired with padding keys / queries (L <= maxpos).
-    auto band_tile = [&](auto QQ) {
-      constexpr int qq = decltype(QQ)::value;
-      int m = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq + l31 + 32 * qq;
-      m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
-      u32x4 e0, e1, e2, e3;  // units half, 2 + half (hi d 0-15 / 16-31), 4 + half, 6 + half (lo)
+    // ---- relative_key band.  Band origin of this wave's row block: band index x of the position <-> table row
+    //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + x,  x = 32 q + (row of tile q); S^T tile t element (key kl, query ql) needs
+    //   x = 32 (T-1-t) + ql - kl + 31.  Rows outside the table (clamped) are only ever paired with padding keys / queries (L <= maxpos).
+    const int mbase = (p.maxpos - 1) - (LP - 1) + LP * (qg - kt) + 32 * wq;
+    auto band_rows = [&](int qq, bool permuted, u32x4 (&e)[4]) {  // units half, 2 + half (hi d 0-15 / 16-31), 4 + half, 6 + half (lo) of the lane's band row
       if constexpr (ELDS) {
-        const unsigned char* erow = (FDMI_ATTN_DBG & 8) ? Es + qq * 4096 + l31 * 16 : Es + m * 128;
-        const int sz = (FDMI_ATTN_DBG & 8) ? 0 : (m >> 1) & 7;
-        e0 = *reinterpret_cast<const u32x4*>(erow + ((half ^ sz) << 4));
-        e1 = *reinterpret_cast<const u32x4*>(erow + (((2 + half) ^ sz) << 4));
-        e2 = *reinterpret_cast<const u32x4*>(erow + (((4 + half) ^ sz) << 4));
-        e3 = *reinterpret_cast<const u32x4*>(erow + (((6 + half) ^ sz) << 4));
+        const unsigned* ea = permuted ? eaddr : eun;
+        e[0] = lds_u128(ea[0] + (unsigned)(qq * 4096));
+        e[1] = lds_u128(ea[1] + (unsigned)(qq * 4096));
+        e[2] = lds_u128(ea[2] + (unsigned)(qq * 4096));
+        e[3] = lds_u128(ea[3] + (unsigned)(qq * 4096));
       } else {
+        int m = mbase + 32 * qq + (permuted ? pi31 : l31);
+        m = m < 0 ? 0 : (m > 2 * (p.maxpos - 1) ? 2 * (p.maxpos - 1) : m);
         const u32x4_t* erow = p.demb + (size_t)m * 8;
-        e0 = erow[half]; e1 = erow[2 + half]; e2 = erow[4 + half]; e3 = erow[6 + half];
+        e[0] = erow[half]; e[1] = erow[2 + half]; e[2] = erow[4 + half]; e[3] = erow[6 + half];
       }
-      f32x16 racc;
-      {
-        const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
-        const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], eh0, zero16, 0, 0, 0);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0], el0, racc, 0, 0, 0);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[0], eh0, racc, 0, 0, 0);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], eh1, racc, 0, 0, 0);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1], el1, racc, 0, 0, 0);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[1], eh1, racc, 0, 0, 0);
+    };
+    auto op_M = [&](auto QQ) {  // R^T tile qq (rows = band rows pi(i), columns = this wave's queries) -> racc[qq & 1]
+      constexpr int qq = decltype(QQ)::value;
+      if (qq >= q0) {
+        u32x4 e[4];
+        band_rows(qq, true, e);
+        const f16x8 eh0 = __builtin_bit_cast(f16x8, e[0]), el0 = __builtin_bit_cast(f16x8, e[2]);
+        const f16x8 eh1 = __builtin_bit_cast(f16x8, e[1]), el1 = __builtin_bit_cast(f16x8, e[3]);
+        f32x16 ra;
+        ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh0, qh[0], zero16, 0, 0, 0);
+        ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(el0, qh[0], ra, 0, 0, 0);
+        ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh0, ql[0], ra, 0, 0, 0);
+        ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh1, qh[1], ra, 0, 0, 0);
+        ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(el1, qh[1], ra, 0, 0, 0);
+        ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh1, ql[1], ra, 0, 0, 0);
+        racc[qq & 1] = ra;
       }
-      // scratch layout [register r][lane] (R row 8q + 4 half + e of lane-column l31 at r * 256 + lane * 4): the 16 stores
-      // are ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR: 2 LDS cycles instead of 4)
-      {
+    };
+    // scratch slot qq & 1 <- racc[qq & 1]: register r of all 64 lanes is ONE ds_write_addtid_b32 (address = M0 + offset + 4 * lane,
+    // no address VGPR: 2 LDS cycles instead of 4) and lands as the two 128-byte band rows 2r, 2r + 1 (see pi31)
+    auto op_W = [&](auto QQ) {
+      constexpr int qq = decltype(QQ)::value;
+      if (qq >= q0) {
+        const f32x16 ra = racc[qq & 1];
+        const unsigned m0v = rw_lds + (unsigned)((qq & 1) * 4096);
         unsigned keep;
         asm volatile(
             // (the MFMA results need 12 wait states before a non-MFMA reader: hipcc pads nothing inside an asm statement)
@@ -309,88 +414,95 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
             "ds_write_addtid_b32 %15 offset:3584\n\tds_write_addtid_b32 %16 offset:3840\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(racc[0]), "v"(racc[1]), "v"(racc[2]), "v"(racc[3]), "v"(racc[4]), "v"(racc[5]), "v"(racc[6]), "v"(racc[7]),
-              "v"(racc[8]), "v"(racc[9]), "v"(racc[10]), "v"(racc[11]), "v"(racc[12]), "v"(racc[13]), "v"(racc[14]), "v"(racc[15]),
-              "s"(rw_lds)
+            : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]), "v"(ra[7]),
+              "v"(ra[8]), "v"(ra[9]), "v"(ra[10]), "v"(ra[11]), "v"(ra[12]), "v"(ra[13]), "v"(ra[14]), "v"(ra[15]),
+              "s"(m0v)
             : "memory");
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // scratch row = query l31 (this lane); band column j = l31 - kl + 31 of the tile PAIR lives in tile q for
-      // j < 32 (l31 <= kl) and in tile q+1, column j - 32, otherwise: both read scratch column j & 31
-      float gth[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-        gth[r] = (FDMI_ATTN_DBG & 4) ? Rw[r * 64 + lane] : Rrow[(l31 - kl + 31) & 31];
-      }
-      // band weights bw_lo / bw_hi (r_ratio where the element belongs to the lower / upper tile of the pair, else 0): one
-      // fma per element and tile instead of a select + fma (band values are finite MFMA sums, so 0 * value = 0)
-      if (qq < T) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[T - 1 - qq][r] = __builtin_fmaf(gth[r], bw_lo[r], sacc[T - 1 - qq][r]);
-      }
-      if (qq > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[T - qq][r] = __builtin_fmaf(gth[r], bw_hi[r], sacc[T - qq][r]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next band tile overwrites this scratch
-      __builtin_amdgcn_wave_barrier();
+    };
+    // relative_key_query: the key term of band tile qq, K_t E_qq^T for the (at most two) S^T tiles t that pair it, through scratch
+    // slot `sl` (free at the call sites below).  Columns = band rows in their natural order: the table rows are re-read un-permuted.
+    auto rkq_tile = [&](auto QQ, int sl) {
+      constexpr int qq = decltype(QQ)::value;
       if constexpr (RKQ) {
-        // the key term against the SAME band tile: S^T tile T-1-qq takes it as its lower tile, S^T tile T-qq as its upper one
-        const f16x8 eh0 = __builtin_bit_cast(f16x8, e0), el0 = __builtin_bit_cast(f16x8, e2);
-        const f16x8 eh1 = __builtin_bit_cast(f16x8, e1), el1 = __builtin_bit_cast(f16x8, e3);
-        const float rk = p.r_scale_k / p.r_scale;  // band weights carry r_scale (k_scale / table scale); this term needs q_scale / table scale
+        if (qq >= q0) {
+          u32x4 e[4];
+          band_rows(qq, false, e);
+          const f16x8 eh0 = __builtin_bit_cast(f16x8, e[0]), el0 = __builtin_bit_cast(f16x8, e[2]);
+          const f16x8 eh1 = __builtin_bit_cast(f16x8, e[1]), el1 = __builtin_bit_cast(f16x8, e[3]);
+          const float rk = p.r_scale_k;  // q_scale / table scale: this term at the raw scale of the scores
+          float* Rk = reinterpret_cast<float*>(Rw + sl * 4096);
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          const int t = side == 0 ? T - 1 - qq : T - qq;
-          if (t < 0 || t >= T) continue;
-          const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
-          const int ksz = (l31 >> 3) & 1;
-          const f16x8 kh0 = *reinterpret_cast<const f16x8*>(pc + (((0 + half) ^ ksz) << 7));
-          const f16x8 kl0 = *reinterpret_cast<const f16x8*>(pc + (((4 + half) ^ ksz) << 7));
-          const f16x8 kh1 = *reinterpret_cast<const f16x8*>(pc + (((2 + half) ^ ksz) << 7));
-          const f16x8 kl1 = *reinterpret_cast<const f16x8*>(pc + (((6 + half) ^ ksz) << 7));
-          f32x16 kacc;
-          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, eh0, zero16, 0, 0, 0);
-          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, el0, kacc, 0, 0, 0);
-          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, eh0, kacc, 0, 0, 0);
-          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, eh1, kacc, 0, 0, 0);
-          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, el1, kacc, 0, 0, 0);
-          kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, eh1, kacc, 0, 0, 0);
-          // scratch [register r][lane]: row (key) 8q + 4 half + e of column l31 at r * 256 + lane * 4 (as above, plain stores)
+          for (int side = 0; side < 2; ++side) {
+            const int t = side == 0 ? T - 1 - qq : T - qq;  // side 0: qq is the lower tile of t's pair, side 1: the upper one
+            if (t < 0 || t >= T || t >= tl) continue;
+            const unsigned char* pc = Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
+            const int ksz = (l31 >> 3) & 1;
+            const f16x8 kh0 = *reinterpret_cast<const f16x8*>(pc + (((0 + half) ^ ksz) << 7));
+            const f16x8 kl0 = *reinterpret_cast<const f16x8*>(pc + (((4 + half) ^ ksz) << 7));
+            const f16x8 kh1 = *reinterpret_cast<const f16x8*>(pc + (((2 + half) ^ ksz) << 7));
+            const f16x8 kl1 = *reinterpret_cast<const f16x8*>(pc + (((6 + half) ^ ksz) << 7));
+            f32x16 kacc;
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, eh0, zero16, 0, 0, 0);
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, el0, kacc, 0, 0, 0);
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, eh0, kacc, 0, 0, 0);
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, eh1, kacc, 0, 0, 0);
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, el1, kacc, 0, 0, 0);
+            kacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, eh1, kacc, 0, 0, 0);
+            // scratch [register r][lane]: row (key) 8q + 4 half + e of column l31 at r * 256 + lane * 4
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Rw[r * 64 + lane] = kacc[r];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int r = 0; r < 16; ++r) Rk[r * 64 + lane] = kacc[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float g = Rw[r * 64 + half * 32 + ((l31 - kl + 31) & 31)] * rk;
-            sacc[t][r] = __builtin_fmaf(g, side == 0 ? bw_lo[r] : bw_hi[r], sacc[t][r]);
+            for (int r = 0; r < 16; ++r) {
+              const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+              const float g = Rk[r * 64 + half * 32 + ((l31 - kl + 31) & 31)];
+              const bool mine = side == 0 ? l31 <= kl : l31 > kl;  // band index l31 - kl + 31 < 32: the pair's lower tile
+              sacc[t][r] = __builtin_fmaf(mine ? g : 0.f, rk, sacc[t][r]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next user overwrites this scratch
+            __builtin_amdgcn_wave_barrier();
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
         }
       }
     };
-    // band tiles 0 .. T in three runs [0, B1) [B1, B2) [B2, T]: the staggered schedule puts a workgroup barrier between them
-    auto band_run = [&](auto LO, auto HI) {
-      constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
-      if constexpr (lo < hi && lo <= T) {
-        band_tile(IC<lo>{});
-        if constexpr (lo + 1 < hi && lo + 1 <= T) band_tile(IC<lo + 1>{});
-        if constexpr (lo + 2 < hi && lo + 2 <= T) band_tile(IC<lo + 2>{});
-        if constexpr (lo + 3 < hi && lo + 3 <= T) band_tile(IC<lo + 3>{});
-        if constexpr (lo + 4 < hi && lo + 4 <= T) band_tile(IC<lo + 4>{});
+    // S^T tile T-1-q += r_scale * band value: ONE ds_read_b32 (immediate offset) and ONE fma per score.  Pair q has its lower tile
+    // in slot q & 1: for even q the 63 band rows are consecutive in the scratch; for odd q the two slots are swapped, so the lanes
+    // whose band index is >= 32 (l31 > kl) start 4096 bytes lower and the others 4096 bytes higher (one v_cndmask per score).
+    auto op_G = [&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      constexpr int t = T - 1 - q;
+      if (q >= q0) {
+        float gth[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int klr = (r & 3) + 8 * (r >> 2);
+          gth[r] = lds_f32(((q & 1) ? godd[r] : gb) + (unsigned)((27 - klr) * 128));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][r] = __builtin_fmaf(gth[r], p.r_scale, sacc[t][r]);
+      }
+      if constexpr (RKQ) {  // slot q & 1 is free now (W(q+2) comes after this); the last pair also frees the other slot
+        rkq_tile(IC<q>{}, q & 1);
+        if constexpr (q == T - 1) rkq_tile(IC<T>{}, T & 1);
       }
     };
-    if (active) {
+    auto band_ops = [&](auto LO, auto HI) {
+      static_for<decltype(LO)::value, decltype(HI)::value>([&](auto I) {
+        constexpr BandOp o = band_op<T>(decltype(I)::value);
+        if constexpr (o.kind == 0) op_M(IC<o.q>{});
+        else if constexpr (o.kind == 1) op_W(IC<o.q>{});
+        else if constexpr (o.kind == 2) op_G(IC<o.q>{});
+        FD_SB();
+      });
+    };
+    if (compute) {
       // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale)
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+        if (t >= tl) continue;
         // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
         const unsigned char* pc = (FDMI_ATTN_DBG & 2) ? Ks + t * 4096 + lane * 16 : Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
         const int ksz = (FDMI_ATTN_DBG & 2) ? 0 : (l31 >> 3) & 1;
@@ -404,36 +516,38 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
           sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
         }
       }
-      if constexpr (REL) band_run(IC<0>{}, IC<B1>{});
+      if constexpr (REL) band_ops(IC<0>{}, IC<BP1>{});
     }
 
     if constexpr (STAG) barrier_keep_vm();  // (staggered schedule: three segments per half position, see the kernel header)
     if constexpr (REL) {
-      if (active) band_run(IC<B1>{}, IC<B2>{});
+      if (compute) band_ops(IC<BP1>{}, IC<BP2>{});
     }
     if constexpr (STAG) barrier_keep_vm();
     if constexpr (REL) {
-      if (active) band_run(IC<B2>{}, IC<T + 1>{});
+      if (compute) band_ops(IC<BP2>{}, IC<NOPS>{});
     }
 
     // ---- [B] every wave is done with K: copy the next position's K, fetch the next item's Q
     FD_STAMP(3);
     barrier_keep_vm();
-    issue_k(nxt);
-    if (nxt_first) load_q(nxt, qn);
+    if (!(FDMI_ATTN_DBG & 64)) {
+      issue_k(nxt);
+      if (nxt_first) load_q(nxt);
+    }
     FD_STAMP(4);
 
-    if (active) {
-      // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one query's scores
+    if (compute) {
+      // mask + online softmax over keys (log2 domain): this lane + its partner (lane ^ 32) hold one query's scores.
+      // Per 32-key tile: entirely below len -> no mask arithmetic at all (a wave-uniform test)
       float mt = -INFINITY;
-      if (r0 + LP <= len) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t) {
+        if (t >= tl) continue;
+        if (r0 + 32 * (t + 1) <= len) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[t][r]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < T; ++t)
+        } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = r0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -443,26 +557,33 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
             sacc[t][r] = sc;
             mt = fmaxf(mt, sc);
           }
+        }
       }
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      mt = pair_max(mt);
       const float m_new = fmaxf(m_run, mt);
-      const float alpha = exp2_neg((m_run - m_new) * s_scale);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
       const float nm = __builtin_fmaf(-m_new, s_scale, 10.0f);   // + log2(PS): p' = PS * 2^((u - m) * s_scale)
       static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
       float psum = 0.f;
 #pragma unroll
-      for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t) {
+        if (t >= tl) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pexp = exp2_neg(__builtin_fmaf(sacc[t][r], s_scale, nm));
           sacc[t][r] = pexp;
           psum += pexp;
         }
-      psum += __shfl_xor(psum, 32);
-      l_run = l_run * alpha + psum;  // carries the factor PS
-      m_run = m_new;
+      }
+      psum = pair_sum(psum);
+      if constexpr (ELDS) {  // a single key tile per item: nothing to rescale
+        l_run = psum;        // carries the factor PS
+      } else {
+        const float alpha = exp2_neg((m_run - m_new) * s_scale);  // first tile: 2^-inf = 0 (accumulators are 0 anyway)
+        l_run = l_run * alpha + psum;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      }
+      m_run = m_new;
     }
 
     // ---- [C] V(p) landed.  Younger: the K pieces (+ Q loads) just issued.
@@ -473,13 +594,14 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     barrier_keep_vm();
     FD_STAMP(6);
 
-    if (active) {
+    if (compute) {
       // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],  B = P (registers),
       //                   key(c, half, j) = 32 t + 16 c + 8 (j>>2) + 4 half + (j&3)   (the C/D row map)
       const unsigned char* vrow = (FDMI_ATTN_DBG & 1) ? Vt + lane * 8 : Vt + (size_t)l31 * 128;
       const int sz = (FDMI_ATTN_DBG & 1) ? 0 : vt_swz(l31);
 #pragma unroll
-      for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t) {
+        if (t >= tl) continue;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           // p = hi + lo, pairwise (img_common.h: split_pair)
@@ -502,28 +624,45 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
           const u32x4 vhu = {vh0[0], vh0[1], vh1[0], vh1[1]};
           const u32x4 vlu = {vl0[0], vl0[1], vl1[0], vl1[1]};
           const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
-          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, oacc, 0, 0, 0);
+          // (tile 0 is always live; ELDS: a single key tile per item, so its first product opens the accumulator)
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, (ELDS && t == 0 && c == 0) ? zero16 : oacc, 0, 0, 0);
           oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, oacc, 0, 0, 0);
           oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, oacc, 0, 0, 0);
         }
+      }
     }
 
     // ---- [D] every wave is done with V: copy the next position's V
     FD_STAMP(7);
     ++slot;
     barrier_keep_vm();
-    issue_v(nxt);
+    if (!(FDMI_ATTN_DBG & 64)) issue_v(nxt);
 
     const bool item_ends = kt + 1 >= cur.nkt;
     if (item_ends) {
       // ctx[row0 + query][head h block] = O^T[d][query] / l_run: register r = 4q + e <-> d = 8q + 4 half + e (quad layout)
       const int l = l0 + l31;
       const bool ok = active && l < nrows;
-      const float onorm = ok ? 1.0f / (p.v_scale * l_run) : 0.f;  // l_run and the accumulator both carry PS
+      const float onorm = p.ctx_scale / (p.v_scale * l_run);  // l_run and the accumulator both carry PS; at the ctx image's scale
       float o[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = ok ? oacc[r] * onorm : 0.f;
-      store_block_g(p.ctx, H, ok ? row0 + l : 0, h, o, p.ctx_scale, half, ok);  // grouped image: the rows of a unit are adjacent
+      for (int r = 0; r < 16; ++r) o[r] = oacc[r] * onorm;
+      // grouped image (the rows of a unit are adjacent): block h of token row row0 + l.  32-bit lane offset into a buffer descriptor
+      // over the image; lanes whose row is no token get an offset beyond the descriptor's range and the hardware drops their
+      // stores (whatever they computed stays in their own lane pair: the half-wave exchange pairs the two halves of ONE query)
+      u32x4 h0, h1, lo0, lo1;
+      pack_block(o, 1.0f, h0, h1, lo0, lo1);
+      const int row = row0 + l;
+      const unsigned voff = ok ? (unsigned)(((((row >> 5) * H + h) * 8 + 2 * half) * 32 + (row & 31)) * 16) : 0xFFFFFF00u;
+      const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0x7FFFF000, 0x00020000);
+      if (FDMI_EPI_DBG != 1 && !(FDMI_ATTN_DBG & 64)) {
+        __builtin_amdgcn_raw_buffer_store_b128(h0, rsc, (int)voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(h1, rsc, (int)voff, 512, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lo0, rsc, (int)voff, 4 * 512, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lo1, rsc, (int)voff, 5 * 512, 0);
+        store_guard(h0, h1);
+        store_guard(lo0, lo1);
+      }
     }
     stored_prev = item_ends;
     if (!done) {
@@ -533,6 +672,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     }
   }
 #undef FD_STAMP
+#undef FD_SB
   if constexpr (STAG) {
     if (grp == 0) {
       barrier_keep_vm();

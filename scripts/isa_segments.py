@@ -33,10 +33,10 @@ def main():
     cur_label = "entry"
     for l in lines[start + 1:end + 1]:
         t = l.strip()
-        if not t or t.startswith((";", ".", "//")):
-            continue
         if re.match(r"^[.\w$]+:", t):
-            if dump: print(t)
+            if dump: print(t.split(";")[0].strip())
+            continue
+        if not t or t.startswith((";", ".", "//")):
             continue
         op = t.split()[0]
         c = classify(op)

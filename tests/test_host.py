@@ -371,3 +371,71 @@ def test_vt_swizzle_is_conflict_free_for_16_lane_groups():
             assert len({ua ^ swz(d) for d in lanes}) == 16
             assert len({ua ^ old(d) for d in lanes}) == 8
     assert sorted(swz(d) for d in range(16)) == list(range(16))
+
+
+def test_relative_key_band_skew_mapping():
+    """The attention kernel's relative_key skew, restated (foldingdiff_amd/csrc/attention_img.hip: op_W / op_G): band tile q is
+    computed as R^T = E Q^T with MFMA row i holding band row pi(i), written with ds_write_addtid_b32 (register r of lane L at
+    slot + 256 r + 4 L) into scratch slot q & 1, and S^T tile T-1-q gathers ONE dword per score from a lane base plus an
+    immediate offset.  Checks, for every pair, lane and register, that the gathered dword is band value (32 q + l - kl + 31, l),
+    that every address stays inside the wave's 8 KiB, and that the gathers are LDS bank-conflict free."""
+    def pi(i):
+        return (i & 24) | ((i & 3) << 1) | ((i >> 2) & 1)
+
+    assert sorted(pi(i) for i in range(32)) == list(range(32))
+    scratch = np.full(2048, np.nan)
+
+    def write_tile(q):
+        for r in range(16):
+            for lane in range(64):
+                j, h = lane & 31, lane >> 5
+                i = 8 * (r >> 2) + 4 * h + (r & 3)                      # MFMA C/D layout: row of register r in half-wave h
+                scratch[((q & 1) * 4096 + r * 256 + lane * 4) // 4] = (32 * q + pi(i)) * 1000 + j
+
+    def gather_pair(q):
+        for r in range(16):
+            klr = (r & 3) + 8 * (r >> 2)
+            for h in (0, 1):
+                banks = set()
+                for l31 in range(32):
+                    kl = klr + 4 * h
+                    gb = (l31 - 4 * h + 4) * 128 + 4 * l31
+                    base = gb if q % 2 == 0 else (gb - 4096 if l31 > kl else gb + 4096)
+                    addr = base + (27 - klr) * 128
+                    assert 0 <= addr < 8192
+                    assert scratch[addr // 4] == (32 * q + l31 - kl + 31) * 1000 + l31, (q, r, h, l31)
+                    banks.add((addr // 4) % 32)
+                assert len(banks) == 32                                   # ds_read_b32: one LDS cycle per 32-lane group
+
+    for T in (1, 2, 3, 4):  # M0 M1 W0 W1 M2 | G0 W2 M3 | G1 W3 M4 | G2 W4 | G3   (tiles beyond T do not exist)
+        scratch[:] = np.nan
+        write_tile(0)
+        write_tile(1)
+        for q in range(T):
+            gather_pair(q)
+            if q + 2 <= T:
+                write_tile(q + 2)
+
+
+def test_relative_key_table_rows_in_lds():
+    """ELDS layout of the distance table (attention_img.hip): LDS row rho holds table row clamp(rho - esh); a wave's band row
+    x of band tile q is LDS row maxpos - LP + esh + 32 wq + 32 q + x.  Every row an ACTIVE wave touches exists (0..255), and
+    every (query, key) pair of real positions reads the table row HF BertSelfAttention names: l - r + maxpos - 1."""
+    for maxpos in (33, 40, 64, 100, 128):
+        for L in range(1, maxpos + 1):
+            T = (L + 31) // 32
+            LP = 32 * T
+            esh = max(0, LP - maxpos)
+            for wq in range(T):
+                rho0 = maxpos - LP + esh + 32 * wq
+                assert rho0 >= 0 and rho0 + 32 * T + 31 <= 255
+                for t in range(T):
+                    q = T - 1 - t
+                    for ql in (0, 13, 31):
+                        for kl in (0, 7, 31):
+                            l, r = 32 * wq + ql, 32 * t + kl
+                            if l >= L or r >= L:
+                                continue
+                            rho = rho0 + 32 * q + (ql - kl + 31)
+                            row = min(max(rho - esh, 0), 2 * maxpos - 2)
+                            assert row == l - r + maxpos - 1
