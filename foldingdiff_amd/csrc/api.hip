@@ -299,7 +299,7 @@ bool expected_shape(const fd_config& c, const std::string& name, std::vector<int
       if (rest == std::string(p) + ".weight") return set({d, d});
       if (rest == std::string(p) + ".bias") return set({d});
     }
-    if (rest == "attention.self.distance_embedding.weight") return set({2 * (int64_t)c.max_pos - 1, kHeadDim});
+    if (rest == "attention.self.distance_embedding.weight") return set({2 * (int64_t)c.max_pos - 1, (int64_t)(c.d_model / c.n_heads)});
     for (const char* p : {"attention.output.LayerNorm", "output.LayerNorm"}) {
       if (rest == std::string(p) + ".weight" || rest == std::string(p) + ".bias") return set({d});
     }
@@ -327,6 +327,10 @@ void drop_workspaces(fd_model* m) {
 }
 
 size_t kHeadBytes(const fd_config& c) { return (size_t)(c.d_model / c.n_heads) * 4; }  // q / k / v image bytes per position and head
+// The q | k | v projections are stored per 32-column SUB-HEAD (d_model / 32 of them; a head of size 32 nb is nb consecutive
+// sub-heads): head size 32 (every released configuration) runs attention_img.hip, 64 / 96 / 128 the general attention_gen.hip.
+int head_dim(const fd_config& c) { return c.d_model / c.n_heads; }
+int sub_heads(const fd_config& c) { return c.d_model / 32; }
 
 int ensure_ws(fd_model* m, int B, int L) {
   Workspace& w = m->ws;
@@ -344,7 +348,7 @@ int ensure_ws(fd_model* m, int B, int L) {
     const bool img = m->img;
     fl[KC_EMBED] = 2 * Md * F * dd;            by[KC_EMBED] = 4 * (Md * F + Md * dd);
     // the row-image path computes V (transposed) in its own launch unless n_heads % 6 == 0 (one q | k | v launch)
-    const int qn = (img && !(c.n_heads % 6 == 0 && !m->split_qkv)) ? 2 : 3;
+    const int qn = (img && !(sub_heads(c) % 6 == 0 && !m->split_qkv)) ? 2 : 3;
     fl[KC_GEMM_QKV] = 2 * Md * qn * dd * dd;
     by[KC_GEMM_QKV] = 4 * (Md * dd + qn * dd * dd + Md * qn * dd);
     fl[KC_GEMM_V] = 2 * Md * dd * dd;          by[KC_GEMM_V] = 4 * (2 * Md * dd + dd * dd);
@@ -409,7 +413,7 @@ int ensure_ws(fd_model* m, int B, int L) {
     w.NKT = L > 128 ? (L + 127) / 128 : 1;
     w.LTOT = w.NKT * w.LPK;
     w.cap = (int)cap;
-    const size_t BH = (size_t)B * c.n_heads, gmax = c.d_ff > c.d_model ? c.d_ff : c.d_model;
+    const size_t BH = (size_t)B * sub_heads(c), gmax = c.d_ff > c.d_model ? c.d_ff : c.d_model;
     HIP_TRY(alz((void**)&w.himg, cap * d * 4));
     HIP_TRY(alz((void**)&w.aimg, cap * d * 4));
     HIP_TRY(alz((void**)&w.cimg, cap * d * 4));
@@ -614,7 +618,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
 #define DBG_STOP() do { if (m->debug_stop > 0 && ++launches >= m->debug_stop) { HIP_TRY(hipGetLastError()); return FD_OK; } } while (0)
   const fd_config& c = m->cfg;
   Workspace& w = m->ws;
-  const int B = w.B, L = w.L, d = c.d_model, ff = c.d_ff, F = c.n_features, H = c.n_heads;
+  const int B = w.B, L = w.L, d = c.d_model, ff = c.d_ff, F = c.n_features, H = sub_heads(c);  // H: 32-column sub-heads (= heads at head size 32)
   const int max_rows = w.cap;
   {
     EmbedImgArgs e;
@@ -682,8 +686,13 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       a.rkq = c.pos_type == FD_POS_RELATIVE_KEY_QUERY;
       a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 : nullptr;
       bool ok = true;
-      PROF(KC_ATTN, ok = launch_attention_img(a, L, s));
-      if (!ok) return fail(FD_E_UNSUPPORTED, "attention: L=%d", L);
+      if (head_dim(c) == 32) {
+        PROF(KC_ATTN, ok = launch_attention_img(a, L, s));
+      } else {  // head size 64 / 96 / 128: the general kernel, indexed by head; the images stay per sub-head
+        a.H = c.n_heads;
+        PROF(KC_ATTN, ok = launch_attention_gen(a, head_dim(c) / 32, s));
+      }
+      if (!ok) return fail(FD_E_UNSUPPORTED, "attention: L=%d, head size %d", L, head_dim(c));
       DBG_STOP();
     }
     {
@@ -1048,8 +1057,13 @@ int fd_create(const fd_config* cfg, int device_id, fd_model** out) {
   *out = nullptr;
   const fd_config& c = *cfg;
   if (c.n_features < 1 || c.n_features > kMaxFeat) return fail(FD_E_INVALID, "n_features=%d outside [1,%d]", c.n_features, kMaxFeat);
-  if (c.n_heads < 1 || c.d_model != c.n_heads * kHeadDim)
-    return fail(FD_E_UNSUPPORTED, "d_model=%d n_heads=%d: attention head size must be %d", c.d_model, c.n_heads, kHeadDim);
+  if (c.n_heads < 1 || c.d_model < 32 || c.d_model % c.n_heads != 0)
+    return fail(FD_E_INVALID, "d_model=%d is not a multiple of n_heads=%d", c.d_model, c.n_heads);
+  {
+    const int hd = c.d_model / c.n_heads;
+    if (hd != 32 && hd != 64 && hd != 96 && hd != 128)
+      return fail(FD_E_UNSUPPORTED, "d_model=%d n_heads=%d: attention head size %d is not one of 32, 64, 96, 128", c.d_model, c.n_heads, hd);
+  }
   if (c.d_model > 1024) return fail(FD_E_UNSUPPORTED, "d_model=%d > 1024", c.d_model);
   if (c.d_ff < 32 || c.d_ff % 32) return fail(FD_E_UNSUPPORTED, "d_ff=%d must be a positive multiple of 32", c.d_ff);
   if (c.n_layers < 1 || c.max_pos < 1) return fail(FD_E_INVALID, "n_layers=%d max_pos=%d", c.n_layers, c.max_pos);
@@ -1098,6 +1112,8 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
   if (!m || !coef || !time_table || !is_angle) return fail(FD_E_INVALID, "null argument");
   if (T < 1) return fail(FD_E_INVALID, "T=%d", T);
   if (precision != FD_PREC_F32 && precision != FD_PREC_F16X3) return fail(FD_E_UNSUPPORTED, "precision mode %d", precision);
+  if (precision == FD_PREC_F32 && head_dim(m->cfg) != kHeadDim)
+    return fail(FD_E_UNSUPPORTED, "head size %d: the exact-fp32 attention kernel is built for head size %d; use FD_PREC_F16X3", head_dim(m->cfg), kHeadDim);
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   drop_workspaces(m);
@@ -1147,7 +1163,7 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
     if (img) {
       if (int rc = upload_split(m, &lw.wqk_i, wqkv.data(), 2 * (int)d, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wv_i, wqkv.data() + 2 * d * d, (int)d, (int)d, 384)) return rc;
-      if (c.n_heads % 6 == 0)
+      if (sub_heads(c) % 6 == 0)
         if (int rc = upload_split(m, &lw.wqkv_i, wqkv.data(), 3 * (int)d, (int)d, 384)) return rc;
       lw.bqk = lw.bqkv;
       lw.bv = lw.bqkv + 2 * d;
@@ -1161,7 +1177,7 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
       NEED(de, p + "attention.self.distance_embedding.weight");
       UP(lw.demb, de);
       if (precision == FD_PREC_F16X3)
-        if (int rc = upload_split(m, &lw.demb_s, de->data.data(), 2 * c.max_pos - 1, kHeadDim)) return rc;
+        if (int rc = upload_split(m, &lw.demb_s, de->data.data(), 2 * c.max_pos - 1, head_dim(c))) return rc;
     }
     NEED(wo, p + "attention.output.dense.weight");
     NEED(bo, p + "attention.output.dense.bias");
@@ -1719,7 +1735,7 @@ int fd_debug_read(fd_model* m, const char* name, float* out, int64_t n_floats) {
   const int li = m->debug_layer < c.n_layers ? m->debug_layer : c.n_layers - 1;
   const LayerDev& lw = m->layers[li];
   const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
-  const long long BH = (long long)w.B * c.n_heads;
+  const long long BH = (long long)w.B * sub_heads(c);
   long long need = 0;
   float* tmp = nullptr;
   auto img = [&](const unsigned char* src, int K, float scale) -> int {

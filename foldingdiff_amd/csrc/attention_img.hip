@@ -135,13 +135,28 @@ template <int T, bool REL, bool ELDS, int NG, bool SAFE, bool PROF = false, bool
 __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   static_assert(REL || !RKQ, "relative_key_query is a relative position type");
   // STAG: group 1 runs HALF A POSITION behind group 0.  A position is two halves of three barrier-separated segments each:
-  //     H1  [A] S^T tiles + band operations [0, BP1)  |  band operations [BP1, BP2)  |  band operations [BP2, end)   (matrix heavy)
-  //     H2  [B] issue K(p+1), softmax                 |  [C] P V                    |  [D] issue V(p+1), ctx store  (VALU heavy)
+  //     H1  [A] ctx store(p-1), copy V(p), S^T tiles + band operations [0, BP1)  |  copy K(p+1), band operations [BP1, BP2)  |  band operations [BP2, end)
+  //     H2  [B] fetch Q(p+1), softmax                                             |  [C] P V                                 |  [D] item bookkeeping
+  // (round 4: cycle stamps showed H2 on the critical path in every segment -- 7.4 k cycles of which ~2.5 k were the ISSUE of its
+  // vector-memory instructions, ~100-200 cycles apiece -- while H1 needed 3.5 k of its 7.1 k: the copies and the ctx store now sit in H1)
   // so on every SIMD one wave is in H1 while the other is in H2: the plain fp32 VALU instructions of the one issue beside the
   // MFMAs of the other (profiles/r03_coissue2_probe.log; this file is compiled with -fno-slp-vectorize, packed fp32 would
   // serialize with the matrix pipe).  In lockstep both waves of a SIMD ran the same phase and the matrix pipe idled through
   // every softmax (29 % MFMA utilisation, cycle stamps).  Group 1 starts with an empty half, group 0 ends with one.
   constexpr bool STAG = FDMI_ATTN_STAG != 0 && NG == 2;
+#ifndef FDMI_ATTN_KEARLY
+#define FDMI_ATTN_KEARLY 1
+#endif
+#ifndef FDMI_ATTN_ILP
+#define FDMI_ATTN_ILP 1  // S^T tiles in pairs and band tiles 0 / 1 together: two independent accumulators alternate on the matrix pipe
+#endif
+#ifndef FDMI_ATTN_VLATE
+#define FDMI_ATTN_VLATE 0  // 1: the V copy and the ctx store wait for barrier [A] of the next position (H1) instead of running behind [D]
+#endif
+  constexpr bool V_LATE = FDMI_ATTN_VLATE != 0;
+  // K(p+1) is copied behind H1's first inner barrier, when every wave of the group has finished S^T(p) -- the band does not read K
+  // (the relative_key_query key term does: there, and without the staggered schedule's inner barriers, the copy waits for [B])
+  constexpr bool K_EARLY = FDMI_ATTN_KEARLY != 0 && STAG && !RKQ;
 #ifndef FDMI_ATTN_DBG
 #define FDMI_ATTN_DBG 0  // ablation builds (wrong results): linear LDS addresses for 1 the V reads, 2 the K reads; 32 no arithmetic (copies, barriers and stores only); 64 no copies / loads / stores in the item loop (arithmetic only)
 #endif
@@ -304,13 +319,39 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   const float mask_raw = -10000.0f * kLog2e / s_scale;                  // (1 - mask) * -10000 at the raw scale
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc;
-  bool stored_prev = false;  // the previous position ended an item (4 ctx stores are younger than its V copy)
+  bool pend = false;         // the previous position ended an item: its ctx block is stored behind barrier [A] of this one
+  unsigned pend_voff = 0;    // ... at this lane offset (beyond the buffer for rows that are no token)
+  float pend_onorm = 0.f;
+  int pend_hoff = 0;
   const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr && grp == 0;
   unsigned long long* st = PROF ? p.stamps + (size_t)wq * 64 * 8 : nullptr;
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define FD_SB() __builtin_amdgcn_sched_barrier(0)
 
+  bool stored_prev = false;  // (!V_LATE) the previous position ended an item: 4 ctx stores are younger than its V copy
+  // ctx[token row][head block] of the item that ended = O^T[d][query] / l_run: register r = 4q + e <-> d = 8q + 4 half + e (quad
+  // layout).  Grouped image (the rows of a unit are adjacent); 32-bit lane offset into a buffer descriptor over the image; lanes
+  // whose row is no token have an offset beyond the descriptor's range and the hardware drops their stores (whatever they computed
+  // stays in their own lane pair: the half-wave exchange pairs the two halves of ONE query)
+  auto flush_ctx = [&]() {
+    if (!pend) return;
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = oacc[r] * pend_onorm;
+    u32x4 h0, h1, lo0, lo1;
+    pack_block(o, 1.0f, h0, h1, lo0, lo1);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0xFFFFFF00u, 0x00020000);
+    if (FDMI_EPI_DBG != 1 && !(FDMI_ATTN_DBG & 64)) {
+      __builtin_amdgcn_raw_buffer_store_b128(h0, rsc, (int)pend_voff, pend_hoff, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(h1, rsc, (int)pend_voff, pend_hoff + 512, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo0, rsc, (int)pend_voff, pend_hoff + 4 * 512, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo1, rsc, (int)pend_voff, pend_hoff + 5 * 512, 0);
+      store_guard(h0, h1);
+      store_guard(lo0, lo1);
+    }
+    pend = false;
+  };
   if constexpr (STAG) {
     if (grp == 1) {  // (its copies of the distance table must have landed before group 0 reads the table behind this barrier)
       FD_WAIT_VM(G::VW);
@@ -339,13 +380,16 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     tl = tl < 1 ? 1 : (tl > T ? T : tl);
     const int q0 = T - tl;  // first band tile any live S^T tile needs
 
-    // ---- [A] K(p) (+ Q(p)) landed.  Younger: V(p) pieces, and the ctx stores of the previous position.
-    if (SAFE) FD_WAIT_VM(0);
+    // ---- [A] K(p) (+ Q(p)) landed.  Younger: nothing (V_LATE), else the V(p) pieces and the ctx stores of the previous position
+    if (SAFE || V_LATE) FD_WAIT_VM(0);
     else if (stored_prev) FD_WAIT_VM(G::VW + 4);
     else FD_WAIT_VM(G::VW);
     FD_STAMP(1);
     barrier_keep_vm();
     FD_STAMP(2);
+    if constexpr (V_LATE) flush_ctx();
+    // every wave of the group passed [D] of the previous position: its V region is free (position 0's copy is in the prologue)
+    if (V_LATE && iter > 0 && !(FDMI_ATTN_DBG & 64)) issue_v(cur);
     if (first_tile) {
       m_run = -INFINITY;
       l_run = 0.f;
@@ -391,6 +435,31 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
         ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(el1, qh[1], ra, 0, 0, 0);
         ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh1, ql[1], ra, 0, 0, 0);
         racc[qq & 1] = ra;
+      }
+    };
+    // M(0) and M(1) together: their accumulators are independent, so the twelve MFMAs alternate instead of forming two dependent
+    // chains of six (H1 is a latency chain: stamps, profiles/r04_attention_stamps_v2.log)
+    auto op_MM = [&]() {
+      if (q0 <= 0) {
+        u32x4 e0[4], e1[4];
+        band_rows(0, true, e0);
+        band_rows(1, true, e1);
+        f32x16 ra = zero16, rb = zero16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, e0[c]), al = __builtin_bit_cast(f16x8, e0[2 + c]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, e1[c]), bl = __builtin_bit_cast(f16x8, e1[2 + c]);
+          ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], ra, 0, 0, 0);
+          rb = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, qh[c], rb, 0, 0, 0);
+          ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], ra, 0, 0, 0);
+          rb = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, qh[c], rb, 0, 0, 0);
+          ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], ra, 0, 0, 0);
+          rb = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ql[c], rb, 0, 0, 0);
+        }
+        racc[0] = ra;
+        racc[1] = rb;
+      } else {
+        op_M(IC<1>{});  // (tile 0 is not needed: q0 >= 1)
       }
     };
     // scratch slot qq & 1 <- racc[qq & 1]: register r of all 64 lanes is ONE ds_write_addtid_b32 (address = M0 + offset + 4 * lane,
@@ -492,34 +561,59 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     auto band_ops = [&](auto LO, auto HI) {
       static_for<decltype(LO)::value, decltype(HI)::value>([&](auto I) {
         constexpr BandOp o = band_op<T>(decltype(I)::value);
-        if constexpr (o.kind == 0) op_M(IC<o.q>{});
+        if constexpr (o.kind == 0 && o.q == 0 && FDMI_ATTN_ILP != 0) op_MM();
+        else if constexpr (o.kind == 0 && o.q == 1 && FDMI_ATTN_ILP != 0) {}
+        else if constexpr (o.kind == 0) op_M(IC<o.q>{});
         else if constexpr (o.kind == 1) op_W(IC<o.q>{});
         else if constexpr (o.kind == 2) op_G(IC<o.q>{});
         FD_SB();
       });
     };
     if (compute) {
-      // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale)
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        if (t >= tl) continue;
+      // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale).
+      // Two tiles at a time (FDMI_ATTN_ILP): their accumulators alternate on the matrix pipe
+      auto kfrag = [&](int t, int c, f16x8& kh, f16x8& kl) {
         // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
         const unsigned char* pc = (FDMI_ATTN_DBG & 2) ? Ks + t * 4096 + lane * 16 : Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
         const int ksz = (FDMI_ATTN_DBG & 2) ? 0 : (l31 >> 3) & 1;
+        kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
+        kl = *reinterpret_cast<const f16x8*>(pc + (((4 + 2 * c + half) ^ ksz) << 7));
+      };
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const f16x8 kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
-          const f16x8 kl = *reinterpret_cast<const f16x8*>(pc + (((4 + 2 * c + half) ^ ksz) << 7));
-          // (the first product starts from the inline constant 0: no accumulator zeroing pass)
-          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
-          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
-          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+      for (int t = 0; t < T; t += (FDMI_ATTN_ILP != 0 ? 2 : 1)) {
+        if (t >= tl) continue;
+        if (FDMI_ATTN_ILP != 0 && t + 1 < T && t + 1 < tl) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            f16x8 kh0, kl0, kh1, kl1;
+            kfrag(t, c, kh0, kl0);
+            kfrag(t + 1, c, kh1, kl1);
+            // (the first product starts from the inline constant 0: no accumulator zeroing pass)
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
+            sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[c], c == 0 ? zero16 : sacc[t + 1], 0, 0, 0);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[c], sacc[t], 0, 0, 0);
+            sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[c], sacc[t + 1], 0, 0, 0);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[c], sacc[t], 0, 0, 0);
+            sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[c], sacc[t + 1], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            f16x8 kh, kl;
+            kfrag(t, c, kh, kl);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+          }
         }
       }
       if constexpr (REL) band_ops(IC<0>{}, IC<BP1>{});
     }
 
     if constexpr (STAG) barrier_keep_vm();  // (staggered schedule: three segments per half position, see the kernel header)
+    if constexpr (K_EARLY) {
+      if (!(FDMI_ATTN_DBG & 64)) issue_k(nxt);
+    }
     if constexpr (REL) {
       if (compute) band_ops(IC<BP1>{}, IC<BP2>{});
     }
@@ -528,11 +622,11 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       if (compute) band_ops(IC<BP2>{}, IC<NOPS>{});
     }
 
-    // ---- [B] every wave is done with K: copy the next position's K, fetch the next item's Q
+    // ---- [B] every wave is done with K and with its Q operands: fetch the next item's Q (and copy the next position's K unless K_EARLY)
     FD_STAMP(3);
     barrier_keep_vm();
     if (!(FDMI_ATTN_DBG & 64)) {
-      issue_k(nxt);
+      if constexpr (!K_EARLY) issue_k(nxt);
       if (nxt_first) load_q(nxt);
     }
     FD_STAMP(4);
@@ -586,7 +680,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       m_run = m_new;
     }
 
-    // ---- [C] V(p) landed.  Younger: the K pieces (+ Q loads) just issued.
+    // ---- [C] V(p) landed.  Younger: the K(p+1) pieces (+ Q loads).
     if (SAFE) FD_WAIT_VM(0);
     else if (nxt_first) FD_WAIT_VM(G::KW + 4);
     else FD_WAIT_VM(G::KW);
@@ -632,45 +726,30 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       }
     }
 
-    // ---- [D] every wave is done with V: copy the next position's V
+    // ---- [D] every wave is done with V: copy the next position's V (V_LATE: behind barrier [A] of the next position)
     FD_STAMP(7);
     ++slot;
     barrier_keep_vm();
-    if (!(FDMI_ATTN_DBG & 64)) issue_v(nxt);
+    if (!V_LATE && !(FDMI_ATTN_DBG & 64)) issue_v(nxt);
 
-    const bool item_ends = kt + 1 >= cur.nkt;
-    if (item_ends) {
-      // ctx[row0 + query][head h block] = O^T[d][query] / l_run: register r = 4q + e <-> d = 8q + 4 half + e (quad layout)
+    stored_prev = kt + 1 >= cur.nkt;
+    if (stored_prev) {  // the item ends: its ctx block leaves now, or (V_LATE) behind the next barrier [A] (oacc is not touched before)
       const int l = l0 + l31;
       const bool ok = active && l < nrows;
-      const float onorm = p.ctx_scale / (p.v_scale * l_run);  // l_run and the accumulator both carry PS; at the ctx image's scale
-      float o[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = oacc[r] * onorm;
-      // grouped image (the rows of a unit are adjacent): block h of token row row0 + l.  32-bit lane offset into a buffer descriptor
-      // over the image; lanes whose row is no token get an offset beyond the descriptor's range and the hardware drops their
-      // stores (whatever they computed stays in their own lane pair: the half-wave exchange pairs the two halves of ONE query)
-      u32x4 h0, h1, lo0, lo1;
-      pack_block(o, 1.0f, h0, h1, lo0, lo1);
       const int row = row0 + l;
-      const unsigned voff = ok ? (unsigned)(((((row >> 5) * H + h) * 8 + 2 * half) * 32 + (row & 31)) * 16) : 0xFFFFFF00u;
-      const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0x7FFFF000, 0x00020000);
-      if (FDMI_EPI_DBG != 1 && !(FDMI_ATTN_DBG & 64)) {
-        __builtin_amdgcn_raw_buffer_store_b128(h0, rsc, (int)voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(h1, rsc, (int)voff, 512, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(lo0, rsc, (int)voff, 4 * 512, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(lo1, rsc, (int)voff, 5 * 512, 0);
-        store_guard(h0, h1);
-        store_guard(lo0, lo1);
-      }
+      pend = true;
+      pend_onorm = p.ctx_scale / (p.v_scale * l_run);  // l_run and the accumulator both carry PS; at the ctx image's scale
+      pend_voff = ok ? (unsigned)((((row >> 5) * H * 8 + 2 * half) * 32 + (row & 31)) * 16) : 0xFFFFFF00u;
+      pend_hoff = h * 4096;  // block h of the row: (.. * H + h) * 8 units * 32 rows * 16 B
+      if constexpr (!V_LATE) flush_ctx();
     }
-    stored_prev = item_ends;
     if (!done) {
       cur = nxt;
       done = is_last(cur);
       advance(nxt);
     }
   }
+  flush_ctx();  // (V_LATE: the stream's last item)
 #undef FD_STAMP
 #undef FD_SB
   if constexpr (STAG) {

@@ -6,7 +6,7 @@
 
 namespace fdmi {
 
-constexpr int kHeadDim = 32;   // d_model / n_heads, fixed by the MFMA tilings
+constexpr int kHeadDim = 32;   // head size of the tuned kernels (attention_img.hip, attention_f32.hip); 64 / 96 / 128: attention_gen.hip
 constexpr int kMaxFeat = 16;   // F <= 16 (reference feature sets have 3..9)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -158,6 +158,8 @@ struct AttnImgArgs {
   unsigned long long* stamps;  // null, or [4 waves][64 slots][8] cycle stamps of workgroup 0 (debug)
 };
 bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s);
+// head sizes 32 * nb, nb = 2, 3, 4 (attention_gen.hip): p.H = heads; qbuf / kbuf / vbuf / ctx / demb are indexed by 32-column sub-head
+bool launch_attention_gen(const AttnImgArgs& p, int nb, hipStream_t s);
 
 struct EmbedImgArgs {
   const float* x;              // [B][L][F]

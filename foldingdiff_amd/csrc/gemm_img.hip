@@ -88,14 +88,26 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   const int Mp = p.dims[1];
   const int tiles_n = (p.N + BN - 1) / BN, ntiles = (Mp / BM) * tiles_n;
   // tiles are dealt XCD-aware, n fastest: the workgroups of one XCD (blockIdx % 8) take neighbouring tiles at
-  // the same time, so the column tiles of one A panel meet in that XCD's L2
+  // the same time, so the column tiles of one A panel meet in that XCD's L2.
+  // Tail (round 4): an XCD's tiles rarely fill whole rounds of its workgroups (BASELINE C3, chunk 0: 315 row panels = 39.4
+  // per XCD for 32 workgroups -- the last round used to keep 7 or 8 of them busy for a whole tile time).  The tiles of an
+  // incomplete last round are cut into S = 2 or 4 ROW SLICES of 64 / 32 rows (as many as the XCD's workgroups can take at
+  // once); a slice runs on the wm 0 waves (the other four only keep the barriers company), streams the whole weight tile but only
+  // its own rows of A, and its epilogue is a half / a quarter of a tile's.  Every epilogue is row-local (LayerNorm included), and
+  // a row's arithmetic does not depend on the slice it is computed in: results are bit-identical with and without the tail.
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
   const int tlo = (int)((long long)ntiles * xcd / 8), thi = (int)((long long)ntiles * (xcd + 1) / 8);
   const int first = tlo + jx, stride = per;
-  const int cnt = first < thi ? (thi - first + stride - 1) / stride : 0;
+#ifndef FDMI_GEMM_TAIL
+#define FDMI_GEMM_TAIL 1  // 0: whole tiles only (rounds 1-3)
+#endif
+  const int nx = thi - tlo, nfull = nx / per, nrem = nx - nfull * per;
+  const int tsplit = (FDMI_GEMM_TAIL && nrem > 0) ? (4 * nrem <= per ? 4 : (2 * nrem <= per ? 2 : 1)) : 1;  // slices per tail tile
+  const bool has_tail = jx < nrem * tsplit;
+  const int cnt = nfull + (has_tail ? 1 : 0);
+  const int tail_tile = tlo + nfull * per + jx / tsplit, tail_slice = jx - (jx / tsplit) * tsplit;
   if (cnt == 0) return;
   const int G = cnt * nk;  // stream positions
-
   {  // bias (all N <= 3 BN columns) or bias | gamma | beta (EPI_LN, N <= BN) -> LDS, published by the first barrier
     float* par = reinterpret_cast<float*>(smem + OFF_PAR);
     if constexpr (EPI == EPI_IMG_LN) {
@@ -119,10 +131,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   }
 
   auto tile_mn = [&](int ti, int& m0, int& n0) {
-    const int tile = first + ti * stride;
-    m0 = (tile / tiles_n) * BM;
+    const bool tail = ti >= nfull;
+    const int tile = tail ? tail_tile : first + ti * stride;
+    m0 = (tile / tiles_n) * BM + (tail ? tail_slice * (BM / tsplit) : 0);
     n0 = (tile - (tile / tiles_n) * tiles_n) * BN;
   };
+  auto tile_rows = [&](int ti) { return ti >= nfull ? BM / tsplit : BM; };  // 128, or 64 / 32 (tail slices)
 
   // ================================================================ the loader waves
   // They issue every LDS-DMA piece of the workgroup: per k-tile 48 W pieces + 16 A pieces of 1 KiB (8 rows x 8 units,
@@ -161,16 +175,27 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         }
       }
     };
+    int a_last = 16 / NL;  // pieces this wave issued for the most recent A stage (a tail slice has 8 or 4 pieces instead of 16)
     auto issue_a = [&]() {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(p.A) + (size_t)a_m0 * rb, 0, BM * rb, 0x00020000);  // the tile's four 32-row groups
+          const_cast<unsigned char*>(p.A) + (size_t)a_m0 * rb, 0, BM * rb, 0x00020000);  // the tile's (up to) four 32-row groups
       lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + a_slot * A_STAGE;
       const int so = a_kt * 4096;
+      const int np = tile_rows(a_ti) >> 3;
+      if (np == 16) {  // (the whole-tile path keeps its straight-line issue: a compare per piece cost ~1.5 % of a q | k | v launch)
 #pragma unroll
-      for (int i = 0; i < 16 / NL; ++i) {
-        const int j = li + i * NL;
-        dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + (j >> 2) * 32 * rb + (j & 3) * 128);
+        for (int i = 0; i < 16 / NL; ++i) {
+          const int j = li + i * NL;
+          dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + (j >> 2) * 32 * rb + (j & 3) * 128);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8 / NL; ++i) {
+          const int j = li + i * NL;
+          if (j < np) dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + (j >> 2) * 32 * rb + (j & 3) * 128);
+        }
       }
+      a_last = np / NL;
       a_slot = a_slot == NAS - 1 ? 0 : a_slot + 1;
       if (a_ti * nk + a_kt + 1 < G) {
         if (++a_kt == nk) {
@@ -181,13 +206,19 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         }
       }
     };
+    // everything but the most recent A stage has landed (counted wait: its immediate is an instruction field)
+    auto wait_all_but_last_a = [&]() {
+      if (a_last == 16 / NL) FD_WAIT_VM(16 / NL);
+      else if (a_last == 8 / NL) FD_WAIT_VM(8 / NL);
+      else FD_WAIT_VM(4 / NL);
+    };
     issue_a();
     issue_w();
     issue_a();
     // The compute waves pass barrier g + 1 BEFORE the last MFMA group of position g (they prefetch the first fragments of
     // g + 1 behind it), so the two barriers of a LayerNorm epilogue follow the barrier of the next tile's first position.
     for (int g = 0, kt = 0; g < G; ++g) {
-      FD_WAIT_VM(16 / NL);
+      wait_all_but_last_a();
       FD_KBAR();
       issue_w();
       issue_a();
@@ -234,11 +265,12 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   // The operands of a group are fetched while the previous group runs, and the barrier of the NEXT position sits before the
   // last group, so the first fragments of the next k-tile are on their way while this one finishes: the matrix pipe
   // never waits for a whole fragment set behind a barrier.
-  auto mm6 = [&](auto SW, const f16x8 (&wf)[3], const f16x8 (&af)[2]) {  // SW: swapped form (D^T = W A^T)
+  // NI: 32-row blocks of the tile this wave computes (2; 1 in the 32-row tail slices)
+  auto mm6 = [&](auto SW, auto NI, const f16x8 (&wf)[3], const f16x8 (&af)[2]) {  // SW: swapped form (D^T = W A^T)
 #pragma unroll
     for (int jn = 0; jn < 3; ++jn)
 #pragma unroll
-      for (int im = 0; im < 2; ++im)
+      for (int im = 0; im < decltype(NI)::value; ++im)
         acc[jn][im] = decltype(SW)::value ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[jn], af[im], acc[jn][im], 0, 0, 0)
                                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], wf[jn], acc[jn][im], 0, 0, 0);
   };
@@ -246,9 +278,9 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
     for (int jn = 0; jn < 3; ++jn) d[jn] = *reinterpret_cast<const f16x8*>(wb + off + jn * 4096);
   };
-  auto lda = [&](f16x8 (&d)[2], const unsigned char* ab, int off) {
+  auto lda = [&](auto NI, f16x8 (&d)[2], const unsigned char* ab, int off) {
 #pragma unroll
-    for (int im = 0; im < 2; ++im) d[im] = *reinterpret_cast<const f16x8*>(ab + off + im * 4096);
+    for (int im = 0; im < decltype(NI)::value; ++im) d[im] = *reinterpret_cast<const f16x8*>(ab + off + im * 4096);
   };
 
   // ---- epilogues.  SWAP form: lane (l31, half) owns token row  m0 + wm*64 + 32 im + l31  and, per MFMA tile jn,
@@ -296,7 +328,8 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   };
   // (the lane indices are re-derived inside the epilogue from an opaque copy: as values that live across the whole tile
   // loop they and everything computed from them get spilled, and a scratch reload behind stores waits for those stores)
-  auto epilogue = [&](auto SW, int ti) {
+  auto epilogue = [&](auto SW, auto NI, int ti) {
+    constexpr int NIM = decltype(NI)::value;  // 32-row blocks of this wave's rows that exist (tail slices of 32 rows: 1)
     constexpr bool kQK = EPI == EPI_IMG_QK || (EPI == EPI_IMG_QKV && decltype(SW)::value);
     constexpr bool kVT = EPI == EPI_IMG_VT || (EPI == EPI_IMG_QKV && !decltype(SW)::value);
     int m0, n0, ln;
@@ -323,7 +356,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = bias4(cb, q, 1.0f);
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int im = 0; im < NIM; ++im) {
           float o[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       // their stores -- no predication, no 64-bit address arithmetic per block (it was ~40 of a block's ~190 VALU instructions).
       unsigned roff[2];
 #pragma unroll
-      for (int im = 0; im < 2; ++im) {
+      for (int im = 0; im < NIM; ++im) {
         const int2 ri = rinfo[im * 32 + l31];
         roff[im] = ri.x >= 0 ? (unsigned)ri.x * (unsigned)(H * p.LTOT * 128) + (unsigned)((ri.y >> 5) * 4096 + (ri.y & 31) * 16 + half * 1024)
                              : 0xFFFFF000u;
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         const float oss = os * (isk ? p.k_scale : p.q_scale);  // (the bias in LDS already carries the image's scale)
         const int hoff = h * p.LTOT * 128;
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int im = 0; im < NIM; ++im) {
           float o[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -451,7 +484,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       // rides in the scalar offset; octets of rows that are no token get an offset beyond the buffer (dropped by the hardware)
       unsigned voff[2][2], voffl[2][2];  // (hi octet, lo octet = four 16-byte pairs further: the hi offset ^ 64, oc < 4)
 #pragma unroll
-      for (int im = 0; im < 2; ++im)
+      for (int im = 0; im < NIM; ++im)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int2 ri = rinfo[im * 32 + 16 * half + 8 * u];
@@ -469,7 +502,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         const float bz = cbg * 32 < 3 * BN ? par0[cbg * 32 + l31] : p.bias[cbg * 32 + l31] * p.v_scale;
         const int hoff = cb * nkb * 4096;
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int im = 0; im < NIM; ++im) {
           float o[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(acc[jn][im][r], osv, bz);
@@ -556,15 +589,16 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
 #define FD_P1(i)                                                                                                         \
   do {                                                                                                                   \
     const u32x4 rh_ = rres[(i) % RD][0], rl_ = rres[(i) % RD][1];                                                        \
-    if constexpr ((i) + RD < 12) request(IC<((i) + RD < 12 ? (i) + RD : 0)>{}, rres[(i) % RD][0], rres[(i) % RD][1]);    \
+    if constexpr ((i) + RD < 6 * NIM) request(IC<((i) + RD < 12 ? (i) + RD : 0)>{}, rres[(i) % RD][0], rres[(i) % RD][1]); \
     pass1_half(IC<((i) % 6) / 2>{}, IC<(i) / 6>{}, IC<(i) % 2>{}, rh_, rl_);                                             \
   } while (0)
-      FD_P1(0); FD_P1(1); FD_P1(2); FD_P1(3); FD_P1(4); FD_P1(5); FD_P1(6); FD_P1(7); FD_P1(8); FD_P1(9); FD_P1(10); FD_P1(11);
+      FD_P1(0); FD_P1(1); FD_P1(2); FD_P1(3); FD_P1(4); FD_P1(5);
+      if constexpr (NIM == 2) { FD_P1(6); FD_P1(7); FD_P1(8); FD_P1(9); FD_P1(10); FD_P1(11); }
 #undef FD_P1
       // row sums: in-lane (48 columns) + the other half-wave + the four N-waves through LDS, fixed order
       auto block_sum = [&](float (&t)[2], float* part) {
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int im = 0; im < NIM; ++im) {
           {  // t += the other half-wave's t: both halves end up with lower + upper (no lane-index register as __shfl_xor needs)
             unsigned lo_side = __builtin_bit_cast(unsigned, t[im]), hi_side = lo_side;
             swap32(lo_side, hi_side);
@@ -574,7 +608,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         }
         barrier_keep_vm();
 #pragma unroll
-        for (int im = 0; im < 2; ++im) {
+        for (int im = 0; im < NIM; ++im) {
           const float4 q4 = *reinterpret_cast<const float4*>(part + (wm * 64 + im * 32 + l31) * 4);
           t[im] = (q4.x + q4.y) + (q4.z + q4.w);
         }
@@ -582,7 +616,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       block_sum(s, red);
       float t2[2] = {0.f, 0.f};
 #pragma unroll
-      for (int im = 0; im < 2; ++im) {
+      for (int im = 0; im < NIM; ++im) {
         const float mean = s[im] * inv_n;
 #pragma unroll
         for (int jn = 0; jn < 3; ++jn) {
@@ -597,7 +631,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       }
       block_sum(t2, red + BM * 4);
 #pragma unroll
-      for (int im = 0; im < 2; ++im) {
+      for (int im = 0; im < NIM; ++im) {
         const float rstd = (1.0f / sqrtf(t2[im] * inv_n + p.eps)) * p.out_scale;  // at the output image's scale (beta in LDS too)
 #pragma unroll
         for (int jn = 0; jn < 3; ++jn) {
@@ -641,10 +675,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     const int r00 = ((ln & 31) >> 3) * 1024 + ((((ln >> 5) ^ ((ln >> 3) & 1)) * 8 + (ln & 7)) << 4);
-    lda(Ya, smem + abase + ca * A_STAGE, r00);
+    lda(IC<2>{}, Ya, smem + abase + ca * A_STAGE, r00);
     ldw(Xa, smem + wbase + cw * W_STAGE, r00);
   };
-  auto groups_1_to_5 = [&](auto SW) {
+  auto groups_1_to_5 = [&](auto SW, auto NI) {
     const unsigned char* wb = smem + wbase + cw * W_STAGE;
     const unsigned char* ab = smem + abase + ca * A_STAGE;
     // the four fragment offsets, re-derived from the lane id per k-tile (8 VALU instructions against ~2900 cycles): as loop
@@ -661,34 +695,34 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           rd[c][pl] = (l31_ >> 3) * 1024 + ((((2 * c + half_ + 4 * pl) ^ ((l31_ >> 3) & 1)) * 8 + (l31_ & 7)) << 4);
     }
     FD_SB();
-    lda(Yb, ab, rd[0][1]);             // al0
+    lda(NI, Yb, ab, rd[0][1]);         // al0
     FD_SB();
-    mm6(SW, Xa, Ya);                   // 1: wh0 ah0
+    mm6(SW, NI, Xa, Ya);               // 1: wh0 ah0
     FD_SB();
     ldw(Xb, wb, rd[0][1]);             // wl0
     FD_SB();
-    mm6(SW, Xa, Yb);                   // 2: wh0 al0
+    mm6(SW, NI, Xa, Yb);               // 2: wh0 al0
     FD_SB();
     ldw(Xa, wb, rd[1][0]);             // wh1
-    lda(Yb, ab, rd[1][0]);             // ah1
+    lda(NI, Yb, ab, rd[1][0]);         // ah1
     FD_SB();
-    mm6(SW, Xb, Ya);                   // 3: wl0 ah0
+    mm6(SW, NI, Xb, Ya);               // 3: wl0 ah0
     FD_SB();
-    lda(Ya, ab, rd[1][1]);             // al1
+    lda(NI, Ya, ab, rd[1][1]);         // al1
     FD_SB();
-    mm6(SW, Xa, Yb);                   // 4: wh1 ah1
+    mm6(SW, NI, Xa, Yb);               // 4: wh1 ah1
     FD_SB();
     ldw(Xb, wb, rd[1][1]);             // wl1
     FD_SB();
-    mm6(SW, Xa, Ya);                   // 5: wh1 al1
+    mm6(SW, NI, Xa, Ya);               // 5: wh1 al1
     FD_SB();
     cw ^= 1;
     ca = ca == NAS - 1 ? 0 : ca + 1;
   };
-  auto run_tile = [&](auto SW, int ti) {
+  auto run_tile = [&](auto SW, auto NI, int ti) {
     for (int kt = 0; kt + 1 < nk; ++kt) {
       FD_STAMP(0);
-      groups_1_to_5(SW);
+      groups_1_to_5(SW, NI);
       FD_STAMP(1);
 #if FDMI_G6FIRST
       FD_WAIT_LGKM0();  // (the same wait as inside the barrier, but visible to the compiler's counter model: no waits in group 6)
@@ -702,7 +736,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       if (wm == 0) first_fragments();
       FD_SB();
       FD_STAMP(3);
-      mm6(SW, Xb, Yb);  // 6: wl1 ah1
+      mm6(SW, NI, Xb, Yb);  // 6: wl1 ah1
       FD_SB();
       if (wm != 0) first_fragments();
       FD_SB();
@@ -710,7 +744,7 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       first_fragments();
       FD_SB();  // reads first: they fly while group 6 runs
       FD_STAMP(3);
-      mm6(SW, Xb, Yb);  // 6: wl1 ah1
+      mm6(SW, NI, Xb, Yb);  // 6: wl1 ah1
       FD_SB();
 #endif
       FD_STAMP(4);
@@ -720,20 +754,36 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     FD_STAMP(0);
     prefetch_rowinfo(SW, ti);
     prefetch_resid(ti);
-    groups_1_to_5(SW);
+    groups_1_to_5(SW, NI);
     FD_STAMP(1);
     const bool stream_end = ti + 1 == cnt;
     if (!stream_end) FD_KBAR();
     FD_STAMP(2);
     FD_STAMP(3);
-    mm6(SW, Xb, Yb);  // 6: wl1 ah1
+    mm6(SW, NI, Xb, Yb);  // 6: wl1 ah1
     FD_SB();
     FD_STAMP(4);
-    epilogue(SW, ti);
+    epilogue(SW, NI, ti);
     FD_STAMP(5);
     zero_acc();
     if (!stream_end) first_fragments();
     ++slot;
+  };
+  // a tail slice (always the LAST tile of a workgroup's stream) is computed by the wm 0 waves; the wm 1 waves execute the tile's
+  // barriers and nothing else: nk - 1 k-loop barriers (the stream's last position has none) and the LayerNorm epilogue's two
+  auto idle_tile = [&]() {
+    for (int kt = 0; kt + 1 < nk; ++kt) FD_KBAR();
+    if constexpr (EPI == EPI_IMG_LN) {
+      barrier_keep_vm();
+      barrier_keep_vm();
+    }
+  };
+  // (one call site per instantiation of run_tile: a second one would turn the k-loop into an out-of-line function)
+  auto do_tile = [&](auto SW, int ti) {
+    const int rows = tile_rows(ti);
+    if (rows != BM && wm != 0) idle_tile();
+    else if (rows == BM / 4) run_tile(SW, IC<1>{}, ti);
+    else run_tile(SW, IC<2>{}, ti);  // 128 rows, or the 64 rows of a half slice (wm 0)
   };
   barrier_keep_vm();  // position 0 landed (also publishes the parameter image)
   first_fragments();
@@ -741,10 +791,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
     if constexpr (EPI == EPI_IMG_QKV) {  // the v tiles run the normal MFMA form (lane = feature), the q | k tiles the swapped one
       int m0, n0;
       tile_mn(ti, m0, n0);
-      if (n0 >= 2 * p.H * 32) run_tile(IC<0>{}, ti);
-      else run_tile(IC<1>{}, ti);
+      if (n0 >= 2 * p.H * 32) do_tile(IC<0>{}, ti);
+      else do_tile(IC<1>{}, ti);
     } else {
-      run_tile(IC<SWAP ? 1 : 0>{}, ti);
+      do_tile(IC<SWAP ? 1 : 0>{}, ti);
     }
   }
 #undef FD_SB

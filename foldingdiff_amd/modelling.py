@@ -13,8 +13,9 @@ Differences from the reference, stated once:
   deterministic eval-mode forward.
 * ``attention_mask`` must be a prefix mask (ones then zeros per row), which is
   what ``p_sample`` builds (sampling.py:56-58).
-* head size (hidden_size / num_attention_heads) must be 32 and
-  ``position_embedding_type`` one of ``absolute`` / ``relative_key``.
+* head size (hidden_size / num_attention_heads) 32 (every released configuration: the tuned kernels), 64, 96 or 128
+  (a general kernel; the HuggingFace default BertConfig the reference's unit tests build has 64), default precision only;
+  ``position_embedding_type`` one of ``absolute`` / ``relative_key`` / ``relative_key_query``.
 """
 import ctypes as C
 import glob

@@ -65,7 +65,7 @@ typedef struct fd_model fd_model;
 typedef struct fd_config {
   int32_t n_features; /* F  = len(ft_is_angular)  (modelling.py:255-256) */
   int32_t d_model;    /* config.hidden_size */
-  int32_t n_heads;    /* config.num_attention_heads; head size must be 32 */
+  int32_t n_heads;    /* config.num_attention_heads; head size d_model / n_heads: 32 (tuned kernels), 64, 96 or 128 */
   int32_t d_ff;       /* config.intermediate_size */
   int32_t n_layers;   /* config.num_hidden_layers */
   int32_t max_pos;    /* config.max_position_embeddings */

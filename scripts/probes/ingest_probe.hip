@@ -243,13 +243,16 @@ int main(int argc, char** argv) {
   a.delay_cycles = 41000 / 32; a.delay_mod = 32;
   run<15>("burst stores, workgroups of an XCD de-phased over one tile period", a, n_cu, ghz);
   a.delay_cycles = 0; a.delay_mod = 1;
-  printf("-- one weight tile for every workgroup (n_wtiles = 1: all 32 CUs of an XCD on the same lines), private A\n");
+  printf("-- which costs more: every workgroup on ONE weight tile (the N = 384 GEMMs) or private A panels (3x the HBM reads)?\n");
   a.n_wtiles = 1; a.a_share = 1;
-  run<1>("+ barrier per stage", a, n_cu, ghz);
+  run<1>("+ barrier: 1 weight tile, private A (attn-out, FFN-down, head)", a, n_cu, ghz);
+  a.n_wtiles = 3; a.a_share = 1;
+  run<1>("+ barrier: 3 weight tiles, private A", a, n_cu, ghz);
+  a.n_wtiles = 1; a.a_share = 3;
+  run<1>("+ barrier: 1 weight tile, A shared by 3", a, n_cu, ghz);
+  a.n_wtiles = 1; a.a_share = 1;
   a.delay_cycles = 450; a.delay_mod = 4;
-  run<1>("+ barrier per stage, workgroups staggered by 0 / 450 / 900 / 1350 cycles", a, n_cu, ghz);
-  a.delay_cycles = 150; a.delay_mod = 12;
-  run<1>("+ barrier per stage, workgroups staggered by (j % 12) x 150 cycles", a, n_cu, ghz);
+  run<1>("+ barrier: 1 weight tile, private A, workgroups staggered by 0 / 450 / 900 / 1350 cycles", a, n_cu, ghz);
   a.delay_cycles = 0; a.delay_mod = 1;
   a.n_wtiles = 3; a.a_share = 3;
   printf("-- K = 768 (24 stages per tile, 1.15 MiB weight tile)\n");
