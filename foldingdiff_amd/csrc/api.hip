@@ -85,6 +85,7 @@ struct Workspace {
   int *seq_row0 = nullptr, *nrow = nullptr, *dims = nullptr, *flag = nullptr;
   hipGraphExec_t graph = nullptr;
   int graph_fuse_ln = -2;  // option value the graph was captured with (-2: none)
+  int graph_varlen = -1;   // ... and the row mode (packed rows launch the slice-capable GEMM instantiation)
   uint64_t last_use = 0;
   void release() {
     if (graph) (void)hipGraphExecDestroy(graph);
@@ -634,6 +635,13 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     HIP_TRY(hipMalloc((void**)&m->stamps, (5 * 8 * 64 * 6 + 4 * 64 * 8) * 8));
     HIP_TRY(hipMemset(m->stamps, 0, (5 * 8 * 64 * 6 + 4 * 64 * 8) * 8));
   }
+  // do the tiles of an N-column GEMM over this workspace fill whole rounds of the launch's workgroups?  Padded rows: the row count
+  // is the workspace's capacity, known here; packed rows (sampling.sample): data dependent -> the slice-capable instantiation
+  auto tail_for = [&](int N) {
+    if (m->varlen) return 1;
+    const int ntiles = (max_rows / 128) * ((N + 383) / 384);
+    return ntiles % gemm_img_grid(max_rows, N) != 0 ? 1 : 0;
+  };
   auto base = [&]() {
     GemmImgArgs g;
     memset(&g, 0, sizeof g);
@@ -653,6 +661,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqkv_i.p); g.bias = lw.bqkv;
       g.qbuf = w.qbuf; g.kbuf = w.kbuf; g.vbuf = w.vbuf; g.N = 3 * d; g.K = d;
       g.acc_scale = 1.0f / (lw.s_h * lw.wqkv_i.scale); g.q_scale = lw.s_q; g.k_scale = lw.s_k; g.v_scale = lw.s_v;
+      g.tail = tail_for(g.N);
       PROF(KC_GEMM_QKV, launch_gemm_img(EPI_IMG_QKV, g, max_rows, s));
       DBG_STOP();
     } else {
@@ -661,6 +670,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
         g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqk_i.p); g.bias = lw.bqk;
         g.qbuf = w.qbuf; g.kbuf = w.kbuf; g.N = 2 * d; g.K = d;
         g.acc_scale = 1.0f / (lw.s_h * lw.wqk_i.scale); g.q_scale = lw.s_q; g.k_scale = lw.s_k;
+        g.tail = tail_for(g.N);
         PROF(KC_GEMM_QKV, launch_gemm_img(EPI_IMG_QK, g, max_rows, s));
         DBG_STOP();
       }
@@ -669,6 +679,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
         g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wv_i.p); g.bias = lw.bv;
         g.vbuf = w.vbuf; g.N = d; g.K = d;
         g.acc_scale = 1.0f / (lw.s_h * lw.wv_i.scale); g.v_scale = lw.s_v;
+        g.tail = tail_for(g.N);
         PROF(KC_GEMM_V, launch_gemm_img(EPI_IMG_VT, g, max_rows, s));
         DBG_STOP();
       }
@@ -701,9 +712,11 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       g.resid = w.himg; g.out = w.aimg; g.N = d; g.K = d;
       g.acc_scale = 1.0f / (lw.s_v * lw.wo_i.scale); g.resid_inv = 1.0f / lw.s_h; g.out_scale = lw.s_a;
       if (d <= 384) {
+        g.tail = tail_for(g.N);
         PROF(KC_GEMM_OUT, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
       } else {  // a LayerNorm row does not fit one 384-column tile: fp32 rows, then the LayerNorm kernel
         g.out_f32 = w.tmp;
+        g.tail = tail_for(g.N);
         PROF(KC_GEMM_OUT, launch_gemm_img(EPI_IMG_BIAS, g, max_rows, s));
         PROF(KC_LN1, launch_ln_f32_img(w.tmp, lw.ln1g, lw.ln1b, c.ln_eps, w.dims, w.aimg, d, lw.s_a, max_rows, s));
       }
@@ -713,6 +726,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       GemmImgArgs g = base();
       g.A = w.aimg; g.W = static_cast<const unsigned char*>(lw.wi_i.p); g.bias = lw.bi; g.out = w.gimg; g.N = ff; g.K = d;
       g.acc_scale = 1.0f / (lw.s_a * lw.wi_i.scale); g.out_scale = lw.s_g;
+      g.tail = tail_for(g.N);
       PROF(KC_GEMM_UP, launch_gemm_img(EPI_IMG_GELU, g, max_rows, s));
       DBG_STOP();
     }
@@ -722,9 +736,11 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       g.resid = w.aimg; g.out = w.himg; g.N = d; g.K = ff;
       g.acc_scale = 1.0f / (lw.s_g * lw.wd_i.scale); g.resid_inv = 1.0f / lw.s_a; g.out_scale = s_next;
       if (d <= 384) {
+        g.tail = tail_for(g.N);
         PROF(KC_GEMM_DOWN, launch_gemm_img(EPI_IMG_LN, g, max_rows, s));
       } else {
         g.out_f32 = w.tmp;
+        g.tail = tail_for(g.N);
         PROF(KC_GEMM_DOWN, launch_gemm_img(EPI_IMG_BIAS, g, max_rows, s));
         PROF(KC_LN2, launch_ln_f32_img(w.tmp, lw.ln2g, lw.ln2b, c.ln_eps, w.dims, w.himg, d, s_next, max_rows, s));
       }
@@ -739,6 +755,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     GemmImgArgs g = base();
     g.A = w.himg; g.W = static_cast<const unsigned char*>(m->hd_w1_i.p); g.bias = m->hd_b1; g.out = w.gimg; g.N = d; g.K = d;
     g.acc_scale = 1.0f / (m->s_hfinal * m->hd_w1_i.scale); g.out_scale = m->s_hg;
+    g.tail = tail_for(g.N);
     PROF(KC_GEMM_HEAD, launch_gemm_img(EPI_IMG_GELU, g, max_rows, s));
       DBG_STOP();
     hi.g = w.gimg; hi.g_inv = 1.0f / m->s_hg;
@@ -811,7 +828,7 @@ int check_lens(const int32_t* lens, int B, int L) {
 
 int ensure_graph(fd_model* m) {
   Workspace& w = m->ws;
-  if (w.graph && w.graph_fuse_ln == m->fuse_ln) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
+  if (w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
   if (w.graph) {
     (void)hipGraphExecDestroy(w.graph);
     w.graph = nullptr;
@@ -840,6 +857,7 @@ int ensure_graph(fd_model* m) {
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess) return fail(FD_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   w.graph_fuse_ln = m->fuse_ln;
+  w.graph_varlen = m->varlen;
   return FD_OK;
 }
 
@@ -941,6 +959,7 @@ int img_gemm_hook(int epilogue, const float* A, const float* W, const float* bia
     out_scale = scale_for(dense_bound(W, bias, 0, N, K, in_l2));
   }
   g.out_scale = out_scale;
+  g.tail = 1;  // (the hook's ragged row counts exercise the tail slices)
   launch_gemm_img(epilogue, g, (int)rows, nullptr);
   launch_img_to_f32(dOi, dC, rows, N, out_scale, nullptr);
   I_TRY(hipGetLastError());
@@ -1329,7 +1348,7 @@ int fd_sample_begin_dev(fd_model* m, const void* x_init_dev, const void* lens_de
   if (m->varlen && full_history)  // packed rows: positions beyond a sequence's length are never written
     HIP_TRY(hipMemsetAsync(out_dev, 0, ((size_t)(t_start + full_history) / full_history) * n * 4, s));
   if (int rc = prepare_rows(m, s, m->varlen)) return rc;
-  if (m->use_graph && !(w.graph && w.graph_fuse_ln == m->fuse_ln)) {
+  if (m->use_graph && !(w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen)) {
     // first use of this (B, L): the warm-up step and the capture run on the model's stream and need the
     // lengths / row table that were just queued on `s`
     if (s != m->stream) HIP_TRY(hipStreamSynchronize(s));

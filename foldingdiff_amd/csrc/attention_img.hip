@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
   // every softmax (29 % MFMA utilisation, cycle stamps).  Group 1 starts with an empty half, group 0 ends with one.
   constexpr bool STAG = FDMI_ATTN_STAG != 0 && NG == 2;
 #ifndef FDMI_ATTN_KEARLY
-#define FDMI_ATTN_KEARLY 1
+#define FDMI_ATTN_KEARLY 0  // (measured: no gain, profiles/r04_attention_ab4.log)
 #endif
 #ifndef FDMI_ATTN_ILP
-#define FDMI_ATTN_ILP 1  // S^T tiles in pairs and band tiles 0 / 1 together: two independent accumulators alternate on the matrix pipe
+#define FDMI_ATTN_ILP 0  // (measured: no gain, profiles/r04_attention_ab4.log)  S^T tiles in pairs and band tiles 0 / 1 together: two independent accumulators alternate on the matrix pipe
 #endif
 #ifndef FDMI_ATTN_VLATE
 #define FDMI_ATTN_VLATE 0  // 1: the V copy and the ctx store wait for barrier [A] of the next position (H1) instead of running behind [D]
@@ -214,9 +214,21 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     s.len = p.lens[s.b];
     s.nkt = (s.len + LP - 1) / LP;  // key tiles holding at least one unmasked key (the rest contribute exactly 0)
   };
+  // item + gstride without the three integer divisions of load_item (scalar divisions are ~25 instructions each, per item and wave):
+  // (b, h, qg) += (gs_b, gs_h, gs_q) with carries
+  const int gs_q = gstride % nqg, gs_h = (gstride / nqg) % H, gs_b = gstride / (nqg * H);
   auto advance = [&](Pos& s) {  // next position; past the end it stays on the last one (copies are repeated, harmlessly)
     if (s.kt + 1 < s.nkt) { ++s.kt; return; }
-    if (s.item + gstride < nitems) load_item(s, s.item + gstride);
+    if (s.item + gstride < nitems) {
+      s.item += gstride;
+      s.kt = 0;
+      int qg = s.qg + gs_q, hh = s.h + gs_h, bb = s.b + gs_b;
+      if (qg >= nqg) { qg -= nqg; ++hh; }
+      if (hh >= H) { hh -= H; ++bb; }
+      s.qg = qg; s.h = hh; s.b = bb;
+      s.len = p.lens[bb];
+      s.nkt = (s.len + LP - 1) / LP;
+    }
   };
   auto is_last = [&](const Pos& s) { return s.kt + 1 >= s.nkt && s.item + gstride >= nitems; };
   // positions of a group's stream (both groups loop to the longer one: the barriers are shared)

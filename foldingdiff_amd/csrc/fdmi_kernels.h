@@ -136,9 +136,11 @@ struct GemmImgArgs {
   float eps;                   // LayerNorm eps
   float q_scale, k_scale, v_scale;
   unsigned long long* stamps;  // null, or [5 epilogues][8 waves][64 slots][6] cycle stamps of workgroup 0 (debug)
+  int tail;                    // 1: the rows may not fill whole rounds of tiles -> the slice-capable instantiation (gemm_img.hip); 0: they do
 };
 // max_rows bounds the grid (B * ceil8(L) of the workspace); the kernel reads the actual count from p.dims.
 void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s);
+int gemm_img_grid(int max_rows, int N);
 
 struct AttnImgArgs {
   const unsigned char* qbuf;

@@ -76,9 +76,11 @@ constexpr int SMEM = OFF_RI + 8 * 512;                          // 160,256 B
 //   first fragment reads, after group 6, after the epilogue (last k-tile of a tile only)}
 // DBG (ablation builds, FDMI_GEMM_DBG, wrong results by design): 1 = no DMA pieces inside the k-loop, 2 = no MFMAs,
 // 3 = no fragment reads + no MFMAs (DMA only)
-template <int EPI, bool SWAP, bool PROF, int DBG = 0>
+// TAIL: 1 = the tile list may end in row slices (below).  Its own instantiation: the slice-capable code is ~1 % slower on its
+// whole-tile path for no visible reason in the loops (same instruction streams; code placement), so launches whose tile count is
+// known on the host to fill whole rounds (BASELINE C2) keep the round-3 code byte for byte.
+template <int EPI, bool SWAP, bool PROF, int TAIL>
 __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
-  static_assert(DBG == 0, "the ablation builds belonged to the all-waves-issue revision (profiles/r02_gemm_ablation.log)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,11 +100,8 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
   const int tlo = (int)((long long)ntiles * xcd / 8), thi = (int)((long long)ntiles * (xcd + 1) / 8);
   const int first = tlo + jx, stride = per;
-#ifndef FDMI_GEMM_TAIL
-#define FDMI_GEMM_TAIL 1  // 0: whole tiles only (rounds 1-3)
-#endif
   const int nx = thi - tlo, nfull = nx / per, nrem = nx - nfull * per;
-  const int tsplit = (FDMI_GEMM_TAIL && nrem > 0) ? (4 * nrem <= per ? 4 : (2 * nrem <= per ? 2 : 1)) : 1;  // slices per tail tile
+  const int tsplit = (TAIL && nrem > 0) ? (4 * nrem <= per ? 4 : (2 * nrem <= per ? 2 : 1)) : 1;  // slices per tail tile
   const bool has_tail = jx < nrem * tsplit;
   const int cnt = nfull + (has_tail ? 1 : 0);
   const int tail_tile = tlo + nfull * per + jx / tsplit, tail_slice = jx - (jx / tsplit) * tsplit;
@@ -175,27 +174,30 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         }
       }
     };
+    // The loaders' instruction stream IS the k-loop's critical path (ten more scalar instructions per stage cost 1 % of a q | k | v
+    // launch): the stages of whole tiles keep the straight-line issue and the constant wait of rounds 2-3 (main loop); only the
+    // last nk + 2 stages of a stream that ends in a tail slice go through the general path.
     int a_last = 16 / NL;  // pieces this wave issued for the most recent A stage (a tail slice has 8 or 4 pieces instead of 16)
-    auto issue_a = [&]() {
+    auto issue_a = [&](auto FULL) {  // FULL: the stage belongs to a whole tile (16 pieces)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<unsigned char*>(p.A) + (size_t)a_m0 * rb, 0, BM * rb, 0x00020000);  // the tile's (up to) four 32-row groups
       lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_A + a_slot * A_STAGE;
       const int so = a_kt * 4096;
-      const int np = tile_rows(a_ti) >> 3;
-      if (np == 16) {  // (the whole-tile path keeps its straight-line issue: a compare per piece cost ~1.5 % of a q | k | v launch)
+      if constexpr (decltype(FULL)::value) {
 #pragma unroll
         for (int i = 0; i < 16 / NL; ++i) {
           const int j = li + i * NL;
           dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + (j >> 2) * 32 * rb + (j & 3) * 128);
         }
       } else {
+        const int np = tile_rows(a_ti) >> 3;
 #pragma unroll
-        for (int i = 0; i < 8 / NL; ++i) {
+        for (int i = 0; i < 16 / NL; ++i) {
           const int j = li + i * NL;
           if (j < np) dma16(rs, dst + j * 1024, (NL & 1) ? ((j & 1) ? va_o : va_e) : va_l, so + (j >> 2) * 32 * rb + (j & 3) * 128);
         }
+        a_last = np / NL;
       }
-      a_last = np / NL;
       a_slot = a_slot == NAS - 1 ? 0 : a_slot + 1;
       if (a_ti * nk + a_kt + 1 < G) {
         if (++a_kt == nk) {
@@ -206,22 +208,35 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
         }
       }
     };
-    // everything but the most recent A stage has landed (counted wait: its immediate is an instruction field)
-    auto wait_all_but_last_a = [&]() {
+    issue_a(IC<0>{});
+    issue_w();
+    issue_a(IC<0>{});
+    // The compute waves pass barrier g + 1 BEFORE the last MFMA group of position g (they prefetch the first fragments of
+    // g + 1 behind it), so the two barriers of a LayerNorm epilogue follow the barrier of the next tile's first position.
+    const bool sliced = has_tail && tsplit > 1;
+    const int g_main = sliced ? (nfull * nk > 2 ? nfull * nk - 2 : 0) : G;  // iteration g issues A(g + 2): whole-tile stages only
+    int g = 0, kt = 0;
+    for (; g < g_main; ++g) {
+      FD_WAIT_VM(16 / NL);
+      FD_KBAR();
+      issue_w();
+      issue_a(IC<1>{});
+      if constexpr (EPI == EPI_IMG_LN) {
+        if (g > 0 && kt == 0) {
+          barrier_keep_vm();
+          barrier_keep_vm();
+        }
+      }
+      if (++kt == nk) kt = 0;
+    }
+    for (; g < G; ++g) {
+      // everything but the most recent A stage has landed (counted wait: its immediate is an instruction field)
       if (a_last == 16 / NL) FD_WAIT_VM(16 / NL);
       else if (a_last == 8 / NL) FD_WAIT_VM(8 / NL);
       else FD_WAIT_VM(4 / NL);
-    };
-    issue_a();
-    issue_w();
-    issue_a();
-    // The compute waves pass barrier g + 1 BEFORE the last MFMA group of position g (they prefetch the first fragments of
-    // g + 1 behind it), so the two barriers of a LayerNorm epilogue follow the barrier of the next tile's first position.
-    for (int g = 0, kt = 0; g < G; ++g) {
-      wait_all_but_last_a();
       FD_KBAR();
       issue_w();
-      issue_a();
+      issue_a(IC<0>{});
       if constexpr (EPI == EPI_IMG_LN) {
         if (g > 0 && kt == 0) {
           barrier_keep_vm();
@@ -319,8 +334,11 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       int m0, n0, ln;
       tile_mn(ti, m0, n0);
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      // (64 rows from the wave's first row; a 32-row tail slice at the very end of the row table has fewer behind it: the range
+      // of the descriptor stops at the table's end -- reading on was a memory fault waiting for an unlucky allocation)
+      const int left = (Mp - (m0 + wm * 64)) * 8;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<int2*>(p.rowinfo + m0 + wm * 64), 0, 512, 0x00020000);
+          const_cast<int2*>(p.rowinfo + m0 + wm * 64), 0, left < 512 ? (left > 0 ? left : 0) : 512, 0x00020000);
       const lds_ptr_t dst = (lds_ptr_t)(smem) + OFF_RI + wid * 512;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 4, ln * 4, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + 256, 4, ln * 4, 256, 0, 0);
@@ -818,21 +836,33 @@ static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    for (const void* f : {reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 0>),
+                          reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, false, 1>),
+                          reinterpret_cast<const void*>(&gemm_img_kernel<EPI, SWAP, true, 1>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set[dev] = true;
   }
   const int ntiles_max = ((max_rows + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   int grid = n_cu_of_current_device() / 8 * 8;
   if (grid > ntiles_max) grid = (ntiles_max + 7) / 8 * 8;
   if (grid < 8) grid = 8;
-  if (p.stamps) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, true>), dim3(grid), dim3(NTHR), SMEM, s, p);
-  else hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false>), dim3(grid), dim3(NTHR), SMEM, s, p);
+  static const int force_tail = [] { const char* e = getenv("FDMI_GEMM_TAIL"); return e ? atoi(e) : -1; }();  // A/B: 0 / 1 override the host's choice
+  const bool tail = force_tail >= 0 ? force_tail != 0 : p.tail != 0;
+  if (p.stamps) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, true, 1>), dim3(grid), dim3(NTHR), SMEM, s, p);
+  else if (tail) hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 1>), dim3(grid), dim3(NTHR), SMEM, s, p);
+  else hipLaunchKernelGGL((gemm_img_kernel<EPI, SWAP, false, 0>), dim3(grid), dim3(NTHR), SMEM, s, p);
 }
 
 }  // namespace gi
+
+// workgroups launch_gemm_img starts for a problem of up to max_rows rows and N columns (the host decides with it whether a
+// launch's tiles fill whole rounds: GemmImgArgs::tail)
+int gemm_img_grid(int max_rows, int N) {
+  const int ntiles_max = ((max_rows + gi::BM - 1) / gi::BM) * ((N + gi::BN - 1) / gi::BN);
+  int grid = gi::n_cu_of_current_device() / 8 * 8;
+  if (grid > ntiles_max) grid = (ntiles_max + 7) / 8 * 8;
+  return grid < 8 ? 8 : grid;
+}
 
 void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s) {
   switch (epilogue) {

@@ -43,6 +43,8 @@ struct Args {
   int store_aux;            // cache policy bits of the output stores (0 plain, 2 nt, 16 sc1, 17 sc0 sc1)
   int store_spread;         // 1: the tile's 24 stores per lane are issued two per stage over the NEXT tile's stages instead of in one burst
   int store_same;           // 1: every tile stores to the same 192 KiB (48 MiB footprint chip-wide instead of 196 MiB)
+  int store_excl;           // 1: no load is in flight while the tile's stores are: the loaders drain (vmcnt 0) and wait at two extra barriers per tile,
+                            //    the consumers issue the burst between them and drain it (vmcnt 0) before the second
 };
 
 // FLAGS: 1 barrier per stage (else free-running loaders), 2 consumer fragment reads, 4 MFMAs, 8 stores per tile
@@ -89,11 +91,18 @@ __global__ __launch_bounds__(640) void probe(Args p) {
     issue_a();
     issue_w();
     issue_a();
+    int lkt = 0;
     for (int g = 0; g < p.stages; ++g) {
       WAIT_VM(8);
       if constexpr (BAR) barrier_keep_vm();
+      if (ST && p.store_excl && g > 0 && lkt == 0) {  // the consumers are about to store the tile that ended with stage g - 1
+        WAIT_VM(0);
+        barrier_keep_vm();  // loads drained -> stores may start
+        barrier_keep_vm();  // stores drained -> loads resume
+      }
       issue_w();
       issue_a();
+      if (++lkt == p.nk) lkt = 0;
     }
     WAIT_VM(0);
   } else {  // ---- consumers
@@ -106,6 +115,19 @@ __global__ __launch_bounds__(640) void probe(Args p) {
     int kt = 0, tile = 0;
     for (int g = 0; g < p.stages; ++g) {
       if constexpr (BAR) barrier_keep_vm();
+      if (ST && p.store_excl && g > 0 && kt == 0) {
+        barrier_keep_vm();
+        {
+          unsigned char* dst = p.out + ((size_t)blockIdx.x * 4 + (p.store_same ? 0 : ((tile - 1) & 3))) * 192 * 1024 + wid * 24 * 1024;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 24 * 1024, 0x00020000);
+          for (int i = 0; i < 24; ++i) {
+            const u32x4 v = {__builtin_bit_cast(unsigned, acc[0][0]), (unsigned)i, (unsigned)g, (unsigned)lane};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16 + i * 1024, 0, 16);
+          }
+        }
+        WAIT_VM(0);
+        barrier_keep_vm();
+      }
       if constexpr (RD || MM) {
         const unsigned char* wb = smem + (g & 1) * W_STAGE + wn * 96 * 128;
         const unsigned char* ab = smem + OFF_A + (g % 3) * A_STAGE + wm * 64 * 128;
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(640) void probe(Args p) {
       if (++kt == p.nk) {
         kt = 0;
         if constexpr (ST) {  // the tile's output: 192 KiB per workgroup = 24 KiB per consumer wave = 24 x 16-byte stores per lane
-          if (!p.store_spread) store_some(0, 24, tile);
+          if (!p.store_spread && !p.store_excl) store_some(0, 24, tile);
         }
         ++tile;
       }
@@ -207,7 +229,7 @@ int main(int argc, char** argv) {
   a.n_wtiles = 3;
   a.a_share = 3;
   a.a_stride = (size_t)(a.stages + 4) * A_STAGE;
-  a.delay_cycles = 0; a.delay_mod = 1; a.store_aux = 16; a.store_spread = 0; a.store_same = 0;
+  a.delay_cycles = 0; a.delay_mod = 1; a.store_aux = 16; a.store_spread = 0; a.store_same = 0; a.store_excl = 0;
   unsigned char *w, *act, *out;
   CHECK(hipMalloc(&w, (size_t)3 * 12 * W_STAGE));
   CHECK(hipMalloc(&act, a.a_stride * n_cu));
@@ -243,6 +265,13 @@ int main(int argc, char** argv) {
   a.delay_cycles = 41000 / 32; a.delay_mod = 32;
   run<15>("burst stores, workgroups of an XCD de-phased over one tile period", a, n_cu, ghz);
   a.delay_cycles = 0; a.delay_mod = 1;
+  a.store_excl = 1;
+  run<15>("EXCLUSIVE store burst (no load in flight while the stores are), lockstep", a, n_cu, ghz);
+  a.delay_cycles = 30000 / 32; a.delay_mod = 32;
+  run<15>("EXCLUSIVE store burst, workgroups of an XCD de-phased over one tile period", a, n_cu, ghz);
+  a.delay_cycles = 30000 / 8; a.delay_mod = 8;
+  run<15>("EXCLUSIVE store burst, 8 phases", a, n_cu, ghz);
+  a.delay_cycles = 0; a.delay_mod = 1; a.store_excl = 0;
   printf("-- which costs more: every workgroup on ONE weight tile (the N = 384 GEMMs) or private A panels (3x the HBM reads)?\n");
   a.n_wtiles = 1; a.a_share = 1;
   run<1>("+ barrier: 1 weight tile, private A (attn-out, FFN-down, head)", a, n_cu, ghz);

@@ -439,3 +439,45 @@ def test_relative_key_table_rows_in_lds():
                             rho = rho0 + 32 * q + (ql - kl + 31)
                             row = min(max(rho - esh, 0), 2 * maxpos - 2)
                             assert row == l - r + maxpos - 1
+
+
+def test_gemm_tile_list_with_tail_slices():
+    """The GEMM kernel's tile list, restated (foldingdiff_amd/csrc/gemm_img.hip: XCD-aware deal + row slices for an XCD's
+    incomplete last round): whatever the tile count and grid, every 32-row block of every (row panel, column tile) is
+    computed exactly once, a workgroup's slice is the last tile of its stream, an XCD never hands out more tail items than it has
+    workgroups, and the whole-tile loader loop never meets a slice stage."""
+    BM = 128
+
+    def tile_list(ntiles, grid, tail=True):
+        per = grid // 8
+        work = []
+        for blk in range(grid):
+            xcd, jx = blk & 7, blk >> 3
+            tlo, thi = ntiles * xcd // 8, ntiles * (xcd + 1) // 8
+            nx = thi - tlo
+            nfull, nrem = nx // per, nx % per
+            tsplit = (4 if 4 * nrem <= per else 2 if 2 * nrem <= per else 1) if (tail and nrem > 0) else 1
+            assert nrem * tsplit <= per
+            has_tail = jx < nrem * tsplit
+            stream = [(tlo + jx + i * per, 0, BM) for i in range(nfull)]
+            if has_tail:
+                stream.append((tlo + nfull * per + jx // tsplit, (jx % tsplit) * (BM // tsplit), BM // tsplit))
+            work.append((stream, nfull, has_tail and tsplit > 1))
+        return work
+
+    for ntiles, grid in [(1, 8), (2, 8), (8, 8), (9, 16), (30, 32), (246, 256), (266, 256), (268, 256), (315, 256), (416, 256),
+                         (512, 256), (630, 256), (804, 256), (945, 256), (1536, 256), (100, 304 // 8 * 8)]:
+        for tail in (True, False):
+            seen = {}
+            for stream, nfull, sliced in tile_list(ntiles, grid, tail):
+                for k, (tile, r0, rows) in enumerate(stream):
+                    assert 0 <= tile < ntiles and rows in (128, 64, 32)
+                    assert rows == BM or k == len(stream) - 1          # a slice ends its workgroup's stream
+                    for blk in range(r0 // 32, (r0 + rows) // 32):
+                        assert (tile, blk) not in seen
+                        seen[(tile, blk)] = 1
+                nk = 12
+                G = len(stream) * nk
+                g_main = max(nfull * nk - 2, 0) if sliced else G         # iteration g issues A(g + 2)
+                assert all((g + 2) // nk < nfull or not sliced for g in range(g_main))
+            assert len(seen) == 4 * ntiles, (ntiles, grid, tail, len(seen))

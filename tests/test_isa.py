@@ -38,20 +38,22 @@ def gemm_asm(tmp_path_factory):
 def _kernels(asm):
     """{(epi, prof): body text} of the gemm_img_kernel instantiations, and their .amdhsa metadata."""
     bodies, meta = {}, {}
-    for m in re.finditer(r"^(_ZN4fdmi2gi15gemm_img_kernelILi(\d)ELb[01]ELb([01])ELi0EEEvNS_11GemmImgArgsE):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm,
+    # template arguments: <epilogue, swapped form, PROF (stamps), TAIL (slice-capable tile list)>; keys (epilogue, prof, tail)
+    for m in re.finditer(r"^(_ZN4fdmi2gi15gemm_img_kernelILi(\d)ELb[01]ELb([01])ELi([01])EEEvNS_11GemmImgArgsE):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm,
                          re.S | re.M):
-        bodies[(int(m.group(2)), int(m.group(3)))] = m.group(4)
-    for m in re.finditer(r"\.name:\s+_ZN4fdmi2gi15gemm_img_kernelILi(\d)ELb[01]ELb([01])ELi0EEEvNS_11GemmImgArgsE\n(.*?)\.wavefront_size",
+        bodies[(int(m.group(2)), int(m.group(3)), int(m.group(4)))] = m.group(5)
+    for m in re.finditer(r"\.name:\s+_ZN4fdmi2gi15gemm_img_kernelILi(\d)ELb[01]ELb([01])ELi([01])EEEvNS_11GemmImgArgsE\n(.*?)\.wavefront_size",
                          asm, re.S):
-        fields = dict(re.findall(r"\.(\w+):\s+(\d+)", m.group(3)))
-        meta[(int(m.group(1)), int(m.group(2)))] = {k: int(v) for k, v in fields.items()}
+        fields = dict(re.findall(r"\.(\w+):\s+(\d+)", m.group(4)))
+        meta[(int(m.group(1)), int(m.group(2)), int(m.group(3)))] = {k: int(v) for k, v in fields.items()}
     return bodies, meta
 
 
 def test_production_gemm_kernels_stay_within_their_scratch_budget(gemm_asm):
     bodies, meta = _kernels(gemm_asm)
-    assert sorted(k[0] for k in meta if k[1] == 0) == sorted(EPI), sorted(meta)
-    for (epi, prof), md in sorted(meta.items()):
+    assert sorted(k[0] for k in meta if k[1] == 0 and k[2] == 0) == sorted(EPI), sorted(meta)
+    assert sorted(k[0] for k in meta if k[1] == 0 and k[2] == 1) == sorted(EPI), sorted(meta)
+    for (epi, prof, tail), md in sorted(meta.items()):
         if prof:
             continue  # the stamp-recording instantiations are debug builds
         assert md["vgpr_count"] <= 168, (EPI[epi], md)   # 10 waves per workgroup: three waves on a SIMD share 512 registers
@@ -62,8 +64,8 @@ def test_k_loops_hold_no_scratch_and_no_vector_memory_wait(gemm_asm):
     """The steady-state k-loop body (30 MFMAs, barrier, 6 MFMAs, backward branch) of every production instantiation:
     no scratch instruction, no s_waitcnt vmcnt (the compute waves have no vector-memory operation in flight there)."""
     bodies, _ = _kernels(gemm_asm)
-    assert sorted(k[0] for k in bodies if k[1] == 0) == sorted(EPI), sorted(bodies)
-    for (epi, prof), text in sorted(bodies.items()):
+    assert sorted(k[0] for k in bodies if k[1] == 0 and k[2] == 0) == sorted(EPI), sorted(bodies)
+    for (epi, prof, tail), text in sorted(bodies.items()):
         if prof:
             continue
         lines = text.splitlines()
