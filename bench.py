@@ -297,8 +297,9 @@ def main():
                        "note": "floors: HBM at the achievable 6.3 TB/s (8 TB/s peak), MFMA at the dense peak of the instruction "
                                "used (3 MFMAs per product in f16x3; a dense MFMA stream on random operands clocks the chip at ~1.6 GHz, "
                                "profiles/r03_clock_probe.log, so the sustained matrix peak is ~2/3 of the 2.4 GHz figure).  Neither floor shows what "
-                               "the probes measured: the GEMM k-loops are bound by the per-CU L2 -> LDS ingest (~2900 cycles per 2304 matrix "
-                               "cycles), and the tile epilogues (VALU + the outputs' HBM writes) run with the matrix pipe idle"},
+                               "the probes measured (profiles/r04_ingest_probe.log): a GEMM tile takes loaded bytes / 35 B/clk + STORED bytes / "
+                               "9.4 B/clk per CU, not overlapping -- the path writes 9.7 GB of activations per timestep at the chip's 4.6 TB/s "
+                               "write rate (~2.1 ms) with the loads and the matrix pipe waiting"},
         "roofline": roofline,
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
                         "launches": v["launches"]} for k, v in kernels.items()},
@@ -367,6 +368,35 @@ def main():
             assert len(res3) == 780 and all(np.isfinite(r).all() for r in res3)
             c3[mode] = {"value": 780 / dt3, "unit": "backbones/s", "seconds": dt3, "passes": 1,
                         "useful_tokens_per_s": useful / dt3}
+        # where C3 loses against C2 per token: per-kernel launch times of its two chunks (packed rows, the sweep's real lengths),
+        # six eager steps with a hipEvent pair per kernel
+        lengths3 = [l for l in range(50, 128) for _ in range(10)]
+        per_chunk = {}
+        for name, these in (("chunk0", lengths3[:512]), ("chunk1", lengths3[512:])):
+            Bc, Lc = len(these), max(these)
+            model.set_option("varlen", 1)
+            xc = torch.randn(Bc, Lc, 6, device=dev)
+            lc = torch.tensor(these, dtype=torch.int32, device=dev)
+            with torch.cuda.stream(side):
+                sampling.sample_on_device(model, xc, lc, betas, seed=1, t_start=1)
+                sync_all()
+                _binding.check(lib.fd_profile_reset(model._handle))
+                _binding.check(lib.fd_profile_every(model._handle, 1))
+                sampling.sample_on_device(model, xc, lc, betas, seed=1, t_start=5)
+                sync_all()
+                _binding.check(lib.fd_profile_every(model._handle, 0))
+            ks, tot = {}, 0.0
+            for i in range(lib.fd_profile_count(model._handle)):
+                _binding.check(lib.fd_profile_get(model._handle, i, C.byref(name_p), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+                if n.value:
+                    ks[name_p.value.decode()] = round(ms.value / n.value * 1e3, 1)
+                    tot += ms.value / 6
+            rows = sum((l + 7) // 8 * 8 for l in these)
+            per_chunk[name] = {"B": Bc, "L": Lc, "useful_tokens": sum(these), "token_rows": rows, "row_panels": -(-rows // 128),
+                               "kernel_us": ks, "ms_per_timestep": round(tot, 3), "useful_tokens_per_us": round(sum(these) / tot / 1e3, 2)}
+        model.set_option("varlen", 0)
+        _binding.check(lib.fd_profile_reset(model._handle))
+        c3["per_chunk"] = per_chunk
         extras["c3"] = c3
         he = {"metric": f"backbones/sec (L={L}, T={T}, bs={B}) through p_sample_loop: host x_init in, final angles out (fd_sample_ex)"}
         x_host = x_init.cpu()
