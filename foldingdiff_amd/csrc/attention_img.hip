@@ -703,6 +703,9 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     if (compute) {
       // O^T += V^T P^T :  A[i = d = l31][position (c, half, j)] = V[key(c,half,j)][d],  B = P (registers),
       //                   key(c, half, j) = 32 t + 16 c + 8 (j>>2) + 4 half + (j&3)   (the C/D row map)
+      // (The per-tile liveness test keeps hipcc from merging the V fetches of two key tiles into ds_read2st64_b64: they are lone
+      // ds_read_b64, which is what vt_swz is conflict free for (img_common.h).  Writing the P V loop in tile pairs to get the merged
+      // instruction back is 8 % SLOWER (101 -> 109 us: more registers and both tiles' split arithmetic in front of the MFMAs).)
       const unsigned char* vrow = (FDMI_ATTN_DBG & 1) ? Vt + lane * 8 : Vt + (size_t)l31 * 128;
       const int sz = (FDMI_ATTN_DBG & 1) ? 0 : vt_swz(l31);
 #pragma unroll

@@ -73,14 +73,18 @@ __device__ __forceinline__ void swap32(unsigned& vdst, unsigned& src) {
 }
 
 // V^T image rows ([b][h][key block][d][128 B = sixteen 8-byte units]): unit u of feature row d sits at position u ^ vt_swz(d).
-// The attention kernel fetches its P V operand with ds_read_b64, lane = d: the LDS serves such a read in groups of 16 lanes
-// against 32 banks (128 bytes), so the 16 rows of a group must hit 16 different 8-byte slots.  ((d >> 1) & 15, chosen for
-// 32-lane groups over 64 banks, cost one extra LDS cycle per group: SQ_LDS_BANK_CONFLICT 3.1 M per launch = 5.4 % of the
-// kernel's cycles, profiles/r03_sq_counters_before_vt_swizzle.txt, r03_attention_notes.log.)
-#ifdef FDMI_VT_SWZ_OLD  // A/B build: the round-2 swizzle
-__device__ __forceinline__ constexpr int vt_swz(int d) { return (d >> 1) & 15; }
-#else
+// The attention kernel fetches its P V operand from LDS with 8-byte reads, lane = d.  Which swizzle is conflict free depends on the
+// INSTRUCTION hipcc picks (SQ_LDS_BANK_CONFLICT, both measured):
+//   * a lone ds_read_b64 is served in 32-lane groups against 64 banks: the 16 even rows of a group share banks 0-31, the 16 odd
+//     ones 32-63, so rows of one parity must name 16 different units -> (d >> 1) & 15.  This is what the kernel emits since round 4
+//     (the per-tile liveness test keeps the fetches of two key tiles apart): 0 conflict cycles against 1.57 M per launch with d & 15
+//     (profiles/r04_attention_lds_conflicts.log; the time is the same: the conflicts hid behind the other wave group);
+//   * ds_read2st64_b64 (two key tiles' fetches merged, rounds 2-3) is served in 16-lane groups against 32 banks: 16 consecutive rows
+//     must name 16 different units -> d & 15 (round 3: 3.1 M conflict cycles -> 0, profiles/r03_attention_notes.log).
+#ifdef FDMI_VT_SWZ_R3  // A/B build: the round-3 swizzle (for merged ds_read2st64_b64 fetches)
 __device__ __forceinline__ constexpr int vt_swz(int d) { return d & 15; }
+#else
+__device__ __forceinline__ constexpr int vt_swz(int d) { return (d >> 1) & 15; }
 #endif
 
 // byte offset of 16-byte unit u (0-3 hi, 4-7 lo) of column block cb of token row `row`; nb = blocks per row

@@ -354,23 +354,29 @@ def test_f16x3_split_arithmetic_is_fp32_class():
         assert (np.abs(back - a)[big] / np.abs(a)[big]).max() <= 2.0 ** -22
 
 
-def test_vt_swizzle_is_conflict_free_for_16_lane_groups():
-    """The V^T rows' unit swizzle (img_common.h: vt_swz) against the LDS model the counters support: a ds_read_b64 is served in
-    16-lane groups against 32 banks, lane l31 reads the 8-byte unit (ua ^ vt_swz(l31)) of its own 128-byte row, so the 16 rows
-    of a group must name 16 different units.  The round-2 swizzle ((d >> 1) & 15) names only 8 (SQ_LDS_BANK_CONFLICT: one
-    extra cycle per group, profiles/r03_attention_notes.log)."""
+def test_vt_swizzle_is_conflict_free_for_the_instruction_emitted():
+    """The V^T rows' unit swizzle (img_common.h: vt_swz) against the LDS models the counters support.  Lane l31 reads the 8-byte
+    unit (ua ^ vt_swz(l31)) of its own 128-byte row.  A lone ds_read_b64 (what the attention kernel emits since round 4) is served
+    in 32-lane groups against 64 banks: rows of one parity share 32 banks, so the 16 even and the 16 odd rows of a group must each
+    name 16 different units -- (d >> 1) & 15 does, d & 15 names 8 (SQ_LDS_BANK_CONFLICT 1.57 M per launch,
+    profiles/r04_attention_lds_conflicts.log).  ds_read2st64_b64 (rounds 2-3: two key tiles' fetches merged) is served in 16-lane
+    groups against 32 banks, where it is the other way round (profiles/r03_attention_notes.log)."""
     import re
     src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "img_common.h")).read()
     m = re.search(r"#else\s*\n__device__ __forceinline__ constexpr int vt_swz\(int d\) \{ return (.*?); \}", src)
     assert m, "vt_swz not found"
     swz = eval("lambda d: " + m.group(1))  # noqa: S307 -- an integer expression of d from our own header
-    old = lambda d: (d >> 1) & 15  # noqa: E731
+    r3 = lambda d: d & 15  # noqa: E731
     for ua in range(16):
-        for g in range(2):
+        for parity in range(2):      # ds_read_b64: 32-lane groups, rows of one parity share a bank half
+            rows = range(parity, 32, 2)
+            assert len({ua ^ swz(d) for d in rows}) == 16
+            assert len({ua ^ r3(d) for d in rows}) == 8
+        for g in range(2):           # ds_read2st64_b64: 16-lane groups against 32 banks
             lanes = range(16 * g, 16 * g + 16)
-            assert len({ua ^ swz(d) for d in lanes}) == 16
-            assert len({ua ^ old(d) for d in lanes}) == 8
-    assert sorted(swz(d) for d in range(16)) == list(range(16))
+            assert len({ua ^ r3(d) for d in lanes}) == 16
+            assert len({ua ^ swz(d) for d in lanes}) == 8
+    assert sorted(swz(d) for d in range(0, 32, 2)) == list(range(16))
 
 
 def test_relative_key_band_skew_mapping():
