@@ -51,6 +51,7 @@ _SIGNATURES = {
     "fd_destroy": (None, [_P]),
     "fd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "fd_forward": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "fd_forward_ex": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "fd_p_sample_step": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "fd_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_uint64, _P, C.c_int]),
     "fd_sample_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_uint64, C.c_int64, _P, C.c_int]),

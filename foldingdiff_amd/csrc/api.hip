@@ -83,6 +83,8 @@ struct Workspace {
                 *vbuf = nullptr, *trash = nullptr;
   int2* rowinfo = nullptr;
   int *seq_row0 = nullptr, *nrow = nullptr, *dims = nullptr, *flag = nullptr;
+  unsigned char* kmask = nullptr;  // [B][L] explicit key mask of fd_forward_ex (allocated on first use)
+  int* pos_ids = nullptr;          // [B][L] explicit position ids of fd_forward_ex (allocated on first use)
   hipGraphExec_t graph = nullptr;
   int graph_fuse_ln = -2;  // option value the graph was captured with (-2: none)
   int graph_varlen = -1;   // ... and the row mode (packed rows launch the slice-capable GEMM instantiation)
@@ -93,7 +95,7 @@ struct Workspace {
     for (void* p : {(void*)x, (void*)eps, (void*)h, (void*)qkv, (void*)ctx, (void*)a, (void*)tmp, (void*)g, (void*)z,
                     (void*)lens, (void*)t_dev, (void*)dyn, (void*)himg, (void*)aimg, (void*)cimg, (void*)gimg,
                     (void*)qbuf, (void*)kbuf, (void*)vbuf, (void*)trash, (void*)rowinfo, (void*)seq_row0, (void*)nrow,
-                    (void*)dims, (void*)flag})
+                    (void*)dims, (void*)flag, (void*)kmask, (void*)pos_ids})
       if (p) (void)hipFree(p);
     *this = Workspace();
   }
@@ -467,6 +469,8 @@ struct StepMode {
   const float* noise = nullptr;
   int t_start = 0;
   bool no_wrap = false;  // p_sample alone, without the loop's wrap
+  const unsigned char* kmask = nullptr;  // fd_forward_ex: [B][L] key mask of any pattern (device), else null: prefix masks from lens
+  const int* pos_ids = nullptr;          // fd_forward_ex: [B][L] position ids of the absolute position embedding (device)
 };
 
 int prof_begin(fd_model* m, int cls, hipStream_t s, bool on) {
@@ -627,6 +631,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     e.x = w.x; e.w_in = m->w_in; e.b_in = m->b_in; e.pos_emb = m->pos_emb; e.gamma = m->emb_g; e.beta = m->emb_b;
     e.time_table = m->time_table; e.tslot = w.t_dev; e.rowinfo = w.rowinfo; e.nrow = w.nrow; e.dims = w.dims;
     e.h = w.himg; e.L = L; e.F = F; e.d = d; e.eps = c.ln_eps; e.out_scale = m->layers[0].s_h;
+    e.pos_ids = mode.pos_ids;
     PROF(KC_EMBED, launch_embed_img(e, max_rows, s));
       DBG_STOP();
   }
@@ -697,7 +702,12 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       a.rkq = c.pos_type == FD_POS_RELATIVE_KEY_QUERY;
       a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 : nullptr;
       bool ok = true;
-      if (head_dim(c) == 32) {
+      if (mode.kmask) {  // an arbitrary key mask: the general kernel (the tuned one builds its schedule on prefix masks)
+        a.H = c.n_heads;
+        a.kmask = mode.kmask;
+        a.L = L;
+        PROF(KC_ATTN, ok = launch_attention_gen(a, head_dim(c) / 32, s));
+      } else if (head_dim(c) == 32) {
         PROF(KC_ATTN, ok = launch_attention_img(a, L, s));
       } else {  // head size 64 / 96 / 128: the general kernel, indexed by head; the images stay per sub-head
         a.H = c.n_heads;
@@ -1304,6 +1314,47 @@ int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, i
   if (int rc = run_step(m, s, mode)) return rc;
   HIP_TRY(hipMemcpyAsync(eps_out, w.eps, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return check_flag(m);
+}
+
+int fd_forward_ex(fd_model* m, const float* x, int t, const uint8_t* key_mask, const int32_t* position_ids, int B, int L,
+                  float* eps_out) {
+  if (int rc = check_shape(m, B, L, t)) return rc;
+  if (!x || !eps_out) return fail(FD_E_INVALID, "null argument");
+  if (!key_mask && !position_ids) return fail(FD_E_INVALID, "fd_forward_ex without a mask and without position ids: use fd_forward");
+  if (!m->img) return fail(FD_E_UNSUPPORTED, "fd_forward_ex (arbitrary key masks / position ids) needs FD_PREC_F16X3");
+  const fd_config& c = m->cfg;
+  if (position_ids && c.pos_type == FD_POS_ABSOLUTE)
+    for (size_t i = 0; i < (size_t)B * L; ++i)
+      if (position_ids[i] < 0 || position_ids[i] >= c.max_pos)
+        return fail(FD_E_INVALID, "position_ids[%zu]=%d outside [0, %d)", i, position_ids[i], c.max_pos);
+  HIP_TRY(hipSetDevice(m->device));
+  if (int rc = ensure_ws(m, B, L)) return rc;
+  Workspace& w = m->ws;
+  const size_t n = (size_t)B * L * c.n_features;
+  hipStream_t s = m->stream;
+  std::vector<int32_t> lens(B, L);  // every position is a row and a key; what is attended to is the mask's business
+  HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(w.lens, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  StepMode mode{};
+  mode.forward_only = true;
+  if (key_mask) {
+    if (!w.kmask) HIP_TRY(hipMalloc((void**)&w.kmask, (size_t)B * L));
+    HIP_TRY(hipMemcpyAsync(w.kmask, key_mask, (size_t)B * L, hipMemcpyHostToDevice, s));
+    mode.kmask = w.kmask;
+  }
+  // (relative position types: the reference's embeddings add no position embedding and HF's distance uses arange, so
+  // position_ids change nothing there -- modelling.py:157-166, BertSelfAttention)
+  if (position_ids && c.pos_type == FD_POS_ABSOLUTE) {
+    if (!w.pos_ids) HIP_TRY(hipMalloc((void**)&w.pos_ids, (size_t)B * L * 4));
+    HIP_TRY(hipMemcpyAsync(w.pos_ids, position_ids, (size_t)B * L * 4, hipMemcpyHostToDevice, s));
+    mode.pos_ids = w.pos_ids;
+  }
+  if (int rc = prepare_rows(m, s, 0)) return rc;
+  if (int rc = set_t(m, s, t)) return rc;
+  if (int rc = run_step(m, s, mode)) return rc;
+  HIP_TRY(hipMemcpyAsync(eps_out, w.eps, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));  // (also keeps `lens` alive until its copy is done)
   return check_flag(m);
 }
 

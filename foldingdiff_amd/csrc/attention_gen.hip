@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void attn_gen_kernel(AttnImgArgs p) {
         : "memory");
   };
 
-  const int nkt = (len + 31) >> 5;  // 32-key tiles holding an unmasked key: the others contribute exactly 0 (exp2 underflows)
+  // 32-key tiles holding an unmasked key: the others contribute exactly 0 (exp2 underflows).  With an explicit key mask (any pattern,
+  // fd_forward_ex) every tile of the Lb positions is visited
+  const unsigned char* km = p.kmask ? p.kmask + (size_t)b * p.L : nullptr;
+  const int nkt = ((km ? Lb : len) + 31) >> 5;
   for (int kt = 0; kt < nkt; ++kt) {
     // ---- S^T tile: rows = keys 32 kt + rowmap(r, half), columns = queries l0 + l31; raw sums at scale q_scale * k_scale
     f32x16 sacc = zero16;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_gen_kernel(AttnImgArgs p) {
 
     // ---- mask + online softmax over the keys (log2 domain): this lane and lane ^ 32 hold one query's scores
     float mt = -INFINITY;
-    if (32 * (kt + 1) <= len) {
+    if (!km && 32 * (kt + 1) <= len) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
     } else {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_gen_kernel(AttnImgArgs p) {
       for (int r = 0; r < 16; ++r) {
         const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
         float sc = sacc[r];
-        if (key >= len) sc += mask_raw;  // (1 - mask) * -10000   (modelling.py:452)
+        if (km ? (key < Lb && km[key] == 0) : key >= len) sc += mask_raw;  // (1 - mask) * -10000   (modelling.py:452)
         if (key >= Lb) sc = -INFINITY;   // not a key at all (rows that do not exist)
         sacc[r] = sc;
         mt = fmaxf(mt, sc);
@@ -289,6 +292,7 @@ static void launch(const AttnImgArgs& p, hipStream_t s) {
 // p.H = heads of size 32 * nb; the q / k / v^T images and ctx are indexed by 32-column sub-head (nb per head)
 bool launch_attention_gen(const AttnImgArgs& p, int nb, hipStream_t s) {
   switch (nb) {
+    case 1: ag::launch<1>(p, s); return true;
     case 2: ag::launch<2>(p, s); return true;
     case 3: ag::launch<3>(p, s); return true;
     case 4: ag::launch<4>(p, s); return true;

@@ -157,10 +157,12 @@ struct AttnImgArgs {
   float r_scale;               // k_scale / scale of the distance table
   float r_scale_k;             // q_scale / scale of the distance table (relative_key_query: the key term)
   int rkq;                     // position_embedding_type == relative_key_query
+  const unsigned char* kmask;  // attention_gen.hip only: [B][L] 1 = attend, 0 = masked key (any pattern), or null: keys >= lens[b] are masked
+  int L;                       // row stride of kmask
   unsigned long long* stamps;  // null, or [4 waves][64 slots][8] cycle stamps of workgroup 0 (debug)
 };
 bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s);
-// head sizes 32 * nb, nb = 2, 3, 4 (attention_gen.hip): p.H = heads; qbuf / kbuf / vbuf / ctx / demb are indexed by 32-column sub-head
+// head sizes 32 * nb, nb = 1 .. 4 (attention_gen.hip; nb = 1 only for arbitrary key masks, which the tuned kernel does not take): p.H = heads; qbuf / kbuf / vbuf / ctx / demb are indexed by 32-column sub-head
 bool launch_attention_gen(const AttnImgArgs& p, int nb, hipStream_t s);
 
 struct EmbedImgArgs {
@@ -169,6 +171,7 @@ struct EmbedImgArgs {
   const float* time_table;
   int* tslot;                  // [0]: step index of this step (host / head_update_img write it), [1]: copy for the step's other kernels
   const int2* rowinfo; const int* nrow; const int* dims;
+  const int* pos_ids;          // [B][L] position ids of the absolute position embedding, or null = 0 .. L-1 (modelling.py:434-442)
   unsigned char* h;            // image [rows128][d/32]
   int L, F, d;
   float eps, out_scale;

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void embed_img_kernel(EmbedImgArgs a) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         float pe[8];
-        load8(a.pos_emb + (size_t)(real ? ri.y : 0) * d + col[j], pe);
+        const int pid = !real ? 0 : (a.pos_ids ? a.pos_ids[(size_t)ri.x * a.L + ri.y] : ri.y);
+        load8(a.pos_emb + (size_t)pid * d + col[j], pe);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[j].v[e] += pe[e];
       }

@@ -11,8 +11,8 @@ Differences from the reference, stated once:
 * eval-mode only.  The reference samples with dropout active because
   ``bin/sample.py`` never calls ``.eval()``; parity here is defined against the
   deterministic eval-mode forward.
-* ``attention_mask`` must be a prefix mask (ones then zeros per row), which is
-  what ``p_sample`` builds (sampling.py:56-58).
+* prefix ``attention_mask``s (ones then zeros per row: what ``p_sample`` builds, sampling.py:56-58) run the tuned kernels;
+  any other mask pattern and explicit ``position_ids`` are honoured too (``fd_forward_ex``, the general attention kernel).
 * head size (hidden_size / num_attention_heads) 32 (every released configuration: the tuned kernels), 64, 96 or 128
   (a general kernel; the HuggingFace default BertConfig the reference's unit tests build has 64), default precision only;
   ``position_embedding_type`` one of ``absolute`` / ``relative_key`` / ``relative_key_query``.
@@ -390,15 +390,15 @@ class BertForDiffusionBase:
 
     # ------------------------------------------------------------------ forward
     @staticmethod
-    def lengths_from_mask(attention_mask: torch.Tensor) -> np.ndarray:
+    def lengths_from_mask(attention_mask: torch.Tensor) -> Optional[np.ndarray]:
+        """Per-sequence lengths of a prefix mask (ones followed by zeros: what p_sample builds, sampling.py:56-58), or None when
+        the mask has any other pattern (the forward then goes through fd_forward_ex and the general attention kernel)."""
         m = attention_mask.detach().cpu()
         assert m.dim() == 2, f"Attention mask expected in shape (batch_size, seq_length), got {m.shape}"
         lens = (m != 0).sum(dim=1)
         prefix = (torch.arange(m.shape[1])[None, :] < lens[:, None])
-        if not torch.equal(prefix, m != 0):
-            raise NotImplementedError("attention_mask must be a prefix mask (ones followed by zeros)")
-        if int(lens.min()) < 1:
-            raise ValueError("every sequence needs at least one unmasked position")
+        if not torch.equal(prefix, m != 0) or int(lens.min()) < 1:
+            return None
         return lens.numpy().astype(np.int32)
 
     def forward(self, inputs: torch.Tensor, timestep: torch.Tensor, attention_mask: torch.Tensor,
@@ -406,38 +406,51 @@ class BertForDiffusionBase:
         """eps = model(x, t, mask): [B, L, F] float32 -> [B, L, F] (modelling.py:384-484).
         Needs the time table: if ``prepare`` was never called, a table long enough for
         max(t)+1 steps is built with the default cosine schedule coefficients (the
-        forward itself does not read them)."""
+        forward itself does not read them).
+
+        Prefix masks with default position ids (everything the sampler produces) run the tuned kernels (``fd_forward``).  Any
+        other ``attention_mask`` pattern and explicit ``position_ids`` (honoured with absolute position embeddings, as in the
+        reference: modelling.py:434-442) go through ``fd_forward_ex``: same arithmetic, the general attention kernel."""
         assert attention_mask is not None
         assert inputs.dim() == 3
+        B, L = int(inputs.shape[0]), int(inputs.shape[1])
+        pids = None
         if position_ids is not None:
-            # the reference honours position_ids with absolute embeddings (modelling.py:434-442); the device kernels
-            # always use 0 .. L-1 -- refuse anything else instead of silently computing a different function
-            want = torch.arange(inputs.shape[1]).expand(inputs.shape[0], -1)
-            try:  # (a broadcastable (1, L) / (L,) arange is what callers usually pass)
-                same = torch.equal(torch.broadcast_to(position_ids.detach().cpu().long(), want.shape), want)
+            want = torch.arange(L).expand(B, -1)
+            try:  # (a broadcastable (1, L) / (L,) tensor is what callers usually pass)
+                got = torch.broadcast_to(position_ids.detach().cpu().long(), want.shape)
             except RuntimeError:
-                same = False
-            if not same:
-                raise NotImplementedError("position_ids other than arange(seq_len) are not supported")
+                raise ValueError(f"position_ids of shape {tuple(position_ids.shape)} do not broadcast to ({B}, {L})")
+            if not torch.equal(got, want) and self.config.position_embedding_type == "absolute":
+                pids = np.ascontiguousarray(got.numpy().astype(np.int32))   # (relative types ignore them, as the reference does)
         lens = self.lengths_from_mask(attention_mask)
         t = timestep.detach().cpu().reshape(-1).long()
-        assert t.numel() == inputs.shape[0]
+        assert t.numel() == B
         need_T = int(t.max()) + 1
         if self._tables_T is None or self._tables_T < need_T:
             self.prepare(beta_schedules.cosine_beta_schedule(max(need_T, 1000)))
         h = self._ensure_handle()
         lib = _binding.load()
         x = np.ascontiguousarray(inputs.detach().cpu().numpy().astype(np.float32))
-        B, L, F = x.shape
-        assert F == self.n_inputs
+        assert x.shape[2] == self.n_inputs
+        kmask = None
+        if lens is None or pids is not None:
+            kmask = np.ascontiguousarray((attention_mask.detach().cpu() != 0).numpy().astype(np.uint8))
         out = np.empty_like(x)
         for tv in torch.unique(t).tolist():  # the device forward takes one t per launch
             rows = np.nonzero((t == tv).numpy())[0]
             xs = np.ascontiguousarray(x[rows])
-            ls = np.ascontiguousarray(lens[rows])
             es = np.empty_like(xs)
-            _binding.check(lib.fd_forward(h, xs.ctypes.data_as(C.c_void_p), int(tv), ls.ctypes.data_as(C.c_void_p),
-                                          len(rows), L, es.ctypes.data_as(C.c_void_p)))
+            if kmask is None:
+                ls = np.ascontiguousarray(lens[rows])
+                _binding.check(lib.fd_forward(h, xs.ctypes.data_as(C.c_void_p), int(tv), ls.ctypes.data_as(C.c_void_p),
+                                              len(rows), L, es.ctypes.data_as(C.c_void_p)))
+            else:
+                ms = np.ascontiguousarray(kmask[rows])
+                ps = np.ascontiguousarray(pids[rows]) if pids is not None else None
+                _binding.check(lib.fd_forward_ex(h, xs.ctypes.data_as(C.c_void_p), int(tv), ms.ctypes.data_as(C.c_void_p),
+                                                 ps.ctypes.data_as(C.c_void_p) if ps is not None else None,
+                                                 len(rows), L, es.ctypes.data_as(C.c_void_p)))
             out[rows] = es
         return torch.from_numpy(out).to(inputs.device)
 

@@ -136,6 +136,15 @@ int fd_set_option(fd_model* m, const char* name, int value);
  * L = 128 at 12 heads) -- FD_E_UNSUPPORTED beyond; sampling.sample chunks by batch_size long before that. */
 int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, float* eps_out);
 
+/* The same forward with what the reference's forward also honours (modelling.py:434-452, :464-467) and the sampler never produces:
+ *   key_mask      uint8[B][L], 1 = attend, 0 = masked key, ANY pattern (NULL: every key is attended to); masked keys get the
+ *                 additive -10000 of HF's extended attention mask, and every position is computed as a query
+ *   position_ids  int32[B][L] rows of the absolute position embedding (NULL: 0 .. L-1); ignored for the relative position
+ *                 types, as in the reference (no position embedding is added there and the distance uses arange)
+ * FD_PREC_F16X3 only.  Arbitrary masks run on the general attention kernel (attention_gen.hip), not the tuned one. */
+int fd_forward_ex(fd_model* m, const float* x, int t, const uint8_t* key_mask, const int32_t* position_ids, int B, int L,
+                  float* eps_out);
+
 /* One reverse step: x_out = p_sample(x, t) (sampling.py:27-75); with wrap != 0 the
  * loop's per-feature wrap to [-pi, pi) (sampling.py:119-130) is applied as well, i.e.
  * the result is one iteration of p_sample_loop.  z is the N(0,1) draw the reference

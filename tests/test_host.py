@@ -137,8 +137,9 @@ def test_argument_validation():
                                       beta_schedule="cosine")
     with pytest.raises(ValueError, match="must be less than"):
         sampling.sample(m, ds, n=1, sweep_lengths=(50, 50))
-    with pytest.raises(NotImplementedError):
-        modelling.BertForDiffusionBase.lengths_from_mask(torch.tensor([[1.0, 0.0, 1.0]]))
+    # masks that are no prefix (or have an all-zero row) are not an error any more: they select the general path (fd_forward_ex)
+    assert modelling.BertForDiffusionBase.lengths_from_mask(torch.tensor([[1.0, 0.0, 1.0]])) is None
+    assert modelling.BertForDiffusionBase.lengths_from_mask(torch.tensor([[0.0, 0.0, 0.0], [1, 1, 1]])) is None
     assert modelling.BertForDiffusionBase.lengths_from_mask(torch.tensor([[1.0, 1.0, 0.0], [1, 1, 1]])).tolist() == [2, 3]
     with pytest.raises(ValueError):
         modelling.BertForDiffusionBase(_mini_cfg(), [True] * 6, decoder="cnn")
