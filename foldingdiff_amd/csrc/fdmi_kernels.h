@@ -141,6 +141,9 @@ struct GemmImgArgs {
 // max_rows bounds the grid (B * ceil8(L) of the workspace); the kernel reads the actual count from p.dims.
 void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s);
 int gemm_img_grid(int max_rows, int N);
+// weight-stationary variant (gemm_ws.hip): K = 384, GELU / bias epilogue
+bool gemm_ws_supported(int epilogue, const GemmImgArgs& p);
+void launch_gemm_ws(int epilogue, const GemmImgArgs& p, hipStream_t s);
 
 struct AttnImgArgs {
   const unsigned char* qbuf;

@@ -865,6 +865,11 @@ int gemm_img_grid(int max_rows, int N) {
 }
 
 void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream_t s) {
+  // Few rows: the weight-stationary kernel (gemm_ws.hip) has no 128-row tile to fill -- a launch costs >= 19 us here (one whole
+  // tile's k-loop per CU) against 8 us there; it wins up to ~12 k rows and ties or loses above (scripts/ws_sweep.py,
+  // profiles/r04_ws_gemm.log).  FDMI_GEMM_WS = 0 never, 1 wherever it applies, unset: by row count.  Same bits either way.
+  static const int ws_mode = [] { const char* e = getenv("FDMI_GEMM_WS"); return e ? atoi(e) : -1; }();
+  if ((ws_mode > 0 || (ws_mode < 0 && max_rows <= 12288)) && !p.stamps && gemm_ws_supported(epilogue, p)) return launch_gemm_ws(epilogue, p, s);
   switch (epilogue) {
     case EPI_IMG_GELU: gi::launch<EPI_IMG_GELU, true>(p, max_rows, s); break;
     case EPI_IMG_LN: gi::launch<EPI_IMG_LN, true>(p, max_rows, s); break;

@@ -127,7 +127,7 @@ def test_the_hazard_scanner_sees_the_pattern_it_is_for():
     assert len(wide_store_hazards(bad)) == 1 and not wide_store_hazards(good)
 
 
-@pytest.mark.parametrize("source", ["gemm_img", "rowwise_img", "attention_img"])
+@pytest.mark.parametrize("source", ["gemm_img", "gemm_ws", "rowwise_img", "attention_img"])
 def test_no_wide_store_is_followed_by_a_write_of_its_data_registers(source, tmp_path):
     flags = fbuild.PER_SOURCE_FLAGS.get(source, [])  # the flags the product build uses for this source
     try:
@@ -166,3 +166,27 @@ def test_the_benchmark_attention_kernel_is_spill_free(tmp_path):
     body = re.search(r"^" + name + r":[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M).group(1)
     assert "scratch_" not in body
     assert "v_pk_fma_f32" not in body and "v_pk_mul_f32" not in body and "v_pk_add_f32" not in body  # packed fp32 serializes with the matrix pipe
+
+
+def test_the_weight_stationary_gemm_keeps_its_weights_in_registers(tmp_path):
+    """gemm_ws_kernel holds a 32-column slice of W as 192 VGPRs for the whole launch, two waves per SIMD (256 registers each):
+    a spill would put weights in scratch and a scratch reload (s_waitcnt vmcnt(0)) inside the counted copy ring."""
+    try:
+        hipcc = fbuild.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    out = tmp_path / "gemm_ws.s"
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include"),
+           "-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, "gemm_ws.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    metas = re.findall(r"\.name:\s+(_ZN4fdmi2ws14gemm_ws_kernelILi\d+EEEvNS_11GemmImgArgsE)\n(.*?)\.wavefront_size", asm, re.S)
+    assert len(metas) == 2, [m[0] for m in metas]   # GELU and plain bias
+    for name, body in metas:
+        md = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", body)}
+        assert md["vgpr_count"] <= 256 and md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
+        text = re.search(rf"^{name}:[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M).group(1)
+        n_mfma = text.count("v_mfma_f32_32x32x16_f16")
+        assert n_mfma >= 72 and n_mfma % 72 == 0, (name, n_mfma)           # whole hand-placed MFMA phases (hipcc may clone the loop)
+        assert "scratch_" not in text, name
