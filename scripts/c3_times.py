@@ -22,7 +22,7 @@ betas = beta_schedules.cosine_beta_schedule(1000)
 h = model.prepare(betas)
 lib = _binding.load()
 lengths = [l for l in range(50, 128) for _ in range(10)]
-chunks = {"c3 chunk 0": lengths[:512], "c3 chunk 1": lengths[512:], "c2": [128] * 512, "c5": [128] * 64}
+chunks = {"c3 chunk 0": lengths[:512], "c3 chunk 1": lengths[512:], "c3 merged": lengths, "c3 merged sorted desc": lengths[::-1], "c2": [128] * 512, "c5": [128] * 64}
 tag = os.environ.get("TAG", "")
 for name, these in chunks.items():
     B, L = len(these), max(these)
