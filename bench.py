@@ -24,6 +24,7 @@ The JSON line also carries
   cpu_baseline  the reference CPU path (oracle restatement, "port") timed on this box's
                 host cores over a bounded sample of the same workload.
   extras.c5     one pass of BASELINE config C5 (L = 512, batch 128, max_position_embeddings = 512).
+  extras.small_batch  step time at batch 1 / 8 / 32 (the few-rows GEMM path)
   extras.c3     BASELINE config C3 through sampling.sample (the reference's published setting), Philox and default noise.
   extras.host_entry  p_sample_loop with host buffers in / out at C2, both noise modes.
 """
@@ -410,6 +411,20 @@ def main():
             he[mode] = {"value": B / dth, "unit": "backbones/s", "seconds": dth, "passes": 1}
         sampling.NOISE_MODE = "philox"
         extras["host_entry"] = he
+        # (c) few sequences at a time (interactive use): every launch is far below one tile per CU there, and the q | k | v, FFN-up
+        # and head-dense1 projections run on the weight-stationary kernel (gemm_ws.hip, launches of <= 12,288 rows)
+        sb = {"metric": f"ms per reverse step at L={L}, released architecture, on-device Philox noise, 50 steps timed", "by_batch": {}}
+        for bs in (1, 8, 32):
+            xs = x_init[:bs].contiguous()
+            ls = torch.full((bs,), L, dtype=torch.int32, device=xs.device)
+            sampling.sample_on_device(model, xs, ls, betas, seed=1, t_start=3)   # workspace + graph of this shape
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            sampling.sample_on_device(model, xs, ls, betas, seed=1, t_start=49)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - ts) * 1e3 / 50
+            sb["by_batch"][str(bs)] = {"ms_per_step": round(ms, 4), "backbones_per_s_at_T1000": round(bs / ms, 2)}
+        extras["small_batch"] = sb
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(B, L, T, shape)
     print(json.dumps(result), flush=True)
