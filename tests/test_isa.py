@@ -182,7 +182,7 @@ def test_the_weight_stationary_gemm_keeps_its_weights_in_registers(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     asm = out.read_text()
     metas = re.findall(r"\.name:\s+(_ZN4fdmi2ws14gemm_ws_kernelILi\d+EEEvNS_11GemmImgArgsE)\n(.*?)\.wavefront_size", asm, re.S)
-    assert len(metas) == 2, [m[0] for m in metas]   # GELU and plain bias
+    assert len(metas) == 3, [m[0] for m in metas]   # GELU, q | k | v and plain bias
     for name, body in metas:
         md = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", body)}
         assert md["vgpr_count"] <= 256 and md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
