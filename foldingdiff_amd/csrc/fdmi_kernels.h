@@ -144,6 +144,9 @@ int gemm_img_grid(int max_rows, int N);
 // weight-stationary variant (gemm_ws.hip): K = 384, GELU / bias epilogue
 bool gemm_ws_supported(int epilogue, const GemmImgArgs& p);
 void launch_gemm_ws(int epilogue, const GemmImgArgs& p, hipStream_t s);
+// few-rows LayerNorm GEMM (gemm_ln_rows.hip): N = 384, K = 384 / 768, one workgroup per 32-row group
+bool gemm_ln_rows_supported(const GemmImgArgs& p);
+void launch_gemm_ln_rows(const GemmImgArgs& p, int max_rows, hipStream_t s);
 
 struct AttnImgArgs {
   const unsigned char* qbuf;

@@ -635,7 +635,8 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
       float t2[2] = {0.f, 0.f};
 #pragma unroll
       for (int im = 0; im < NIM; ++im) {
-        const float mean = s[im] * inv_n;
+        float mean = s[im] * inv_n;
+        asm volatile("" : "+v"(mean));  // (a value, not a product: `acc - mean` must not become an fma in one kernel and not in the other)
 #pragma unroll
         for (int jn = 0; jn < 3; ++jn) {
           if (wn * 3 + jn >= nb) continue;
@@ -643,14 +644,14 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           for (int r = 0; r < 16; ++r) {
             const float dl = acc[jn][im][r] - mean;
             acc[jn][im][r] = dl;
-            t2[im] += dl * dl;
+            t2[im] = __builtin_fmaf(dl, dl, t2[im]);  // (spelled out: the few-rows kernel, gemm_ln_rows.hip, must round exactly alike)
           }
         }
       }
       block_sum(t2, red + BM * 4);
 #pragma unroll
       for (int im = 0; im < NIM; ++im) {
-        const float rstd = (1.0f / sqrtf(t2[im] * inv_n + p.eps)) * p.out_scale;  // at the output image's scale (beta in LDS too)
+        const float rstd = (1.0f / sqrtf(__builtin_fmaf(t2[im], inv_n, p.eps))) * p.out_scale;  // at the output image's scale (beta in LDS too)
 #pragma unroll
         for (int jn = 0; jn < 3; ++jn) {
           const int cb = wn * 3 + jn;
@@ -660,10 +661,10 @@ __global__ __launch_bounds__(NTHR) void gemm_img_kernel(GemmImgArgs p) {
           for (int q = 0; q < 4; ++q) {
             const float4 g4 = *reinterpret_cast<const float4*>(par + BN + cb * 32 + 8 * q + 4 * half);
             const float4 e4 = *reinterpret_cast<const float4*>(par + 2 * BN + cb * 32 + 8 * q + 4 * half);
-            o[4 * q + 0] = acc[jn][im][4 * q + 0] * rstd * g4.x + e4.x;
-            o[4 * q + 1] = acc[jn][im][4 * q + 1] * rstd * g4.y + e4.y;
-            o[4 * q + 2] = acc[jn][im][4 * q + 2] * rstd * g4.z + e4.z;
-            o[4 * q + 3] = acc[jn][im][4 * q + 3] * rstd * g4.w + e4.w;
+            o[4 * q + 0] = __builtin_fmaf(acc[jn][im][4 * q + 0] * rstd, g4.x, e4.x);
+            o[4 * q + 1] = __builtin_fmaf(acc[jn][im][4 * q + 1] * rstd, g4.y, e4.y);
+            o[4 * q + 2] = __builtin_fmaf(acc[jn][im][4 * q + 2] * rstd, g4.z, e4.z);
+            o[4 * q + 3] = __builtin_fmaf(acc[jn][im][4 * q + 3] * rstd, g4.w, e4.w);
           }
           store_group_block(p.out + ((size_t)((m0 + wm * 64 + im * 32) >> 5) * nb + cb) * 4096, o, 1.0f, l31, half);
         }
@@ -870,6 +871,10 @@ void launch_gemm_img(int epilogue, const GemmImgArgs& p, int max_rows, hipStream
   // profiles/r04_ws_gemm.log).  FDMI_GEMM_WS = 0 never, 1 wherever it applies, unset: by row count.  Same bits either way.
   static const int ws_mode = [] { const char* e = getenv("FDMI_GEMM_WS"); return e ? atoi(e) : -1; }();
   if ((ws_mode > 0 || (ws_mode < 0 && max_rows <= 12288)) && !p.stamps && gemm_ws_supported(epilogue, p)) return launch_gemm_ws(epilogue, p, s);
+  // ... and the LayerNorm GEMMs of few rows on gemm_ln_rows.hip (a workgroup per 32-row group, weights straight from L2 to registers)
+  static const int ln_rows_max = [] { const char* e = getenv("FDMI_LN_ROWS_MAX"); return e ? atoi(e) : 8192; }();
+  if (epilogue == EPI_IMG_LN && ws_mode != 0 && max_rows <= (ws_mode > 0 ? (1 << 30) : ln_rows_max) && !p.stamps && gemm_ln_rows_supported(p))
+    return launch_gemm_ln_rows(p, max_rows, s);
   switch (epilogue) {
     case EPI_IMG_GELU: gi::launch<EPI_IMG_GELU, true>(p, max_rows, s); break;
     case EPI_IMG_LN: gi::launch<EPI_IMG_LN, true>(p, max_rows, s); break;

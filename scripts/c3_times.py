@@ -22,11 +22,11 @@ betas = beta_schedules.cosine_beta_schedule(1000)
 h = model.prepare(betas)
 lib = _binding.load()
 lengths = [l for l in range(50, 128) for _ in range(10)]
-chunks = {"c3 chunk 0": lengths[:512], "c3 chunk 1": lengths[512:], "c3 merged": lengths, "c3 merged sorted desc": lengths[::-1], "c2": [128] * 512, "c5": [128] * 64}
+chunks = {"c3 chunk 0": lengths[:512], "c3 chunk 1": lengths[512:], "c3 merged": lengths, "c3 merged sorted desc": lengths[::-1], "c2": [128] * 512, "c5": [128] * 64, "b8": [128] * 8}
 tag = os.environ.get("TAG", "")
 for name, these in chunks.items():
     B, L = len(these), max(these)
-    packed = 0 if name in ("c2", "c5") else 1
+    packed = 0 if name in ("c2", "c5", "b8") else 1
     model.set_option("varlen", packed)
     x = torch.randn(B, L, 6, device="cuda:0")
     lens = torch.tensor(these, dtype=torch.int32, device="cuda:0")
