@@ -127,7 +127,7 @@ def test_the_hazard_scanner_sees_the_pattern_it_is_for():
     assert len(wide_store_hazards(bad)) == 1 and not wide_store_hazards(good)
 
 
-@pytest.mark.parametrize("source", ["gemm_img", "gemm_ws", "rowwise_img", "attention_img"])
+@pytest.mark.parametrize("source", ["gemm_img", "gemm_ws", "gemm_ln_rows", "rowwise_img", "attention_img"])
 def test_no_wide_store_is_followed_by_a_write_of_its_data_registers(source, tmp_path):
     flags = fbuild.PER_SOURCE_FLAGS.get(source, [])  # the flags the product build uses for this source
     try:
@@ -190,3 +190,21 @@ def test_the_weight_stationary_gemm_keeps_its_weights_in_registers(tmp_path):
         n_mfma = text.count("v_mfma_f32_32x32x16_f16")
         assert n_mfma >= 72 and n_mfma % 72 == 0, (name, n_mfma)           # whole hand-placed MFMA phases (hipcc may clone the loop)
         assert "scratch_" not in text, name
+
+
+def test_the_few_rows_layernorm_gemm_is_spill_free(tmp_path):
+    """gemm_ln_rows_kernel<12 / 24>: three rotating weight buffers (144 VGPRs) beside 48 accumulator registers, one wave per SIMD."""
+    try:
+        hipcc = fbuild.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    out = tmp_path / "gemm_ln_rows.s"
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include"),
+           "-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, "gemm_ln_rows.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    metas = re.findall(r"\.name:\s+(_ZN4fdmi2lr19gemm_ln_rows_kernelILi\d+EEEvNS_11GemmImgArgsE)\n(.*?)\.wavefront_size", out.read_text(), re.S)
+    assert len(metas) == 2, [m[0] for m in metas]   # K = 384 and K = 768
+    for name, body in metas:
+        md = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", body)}
+        assert md["vgpr_count"] <= 512 and md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
