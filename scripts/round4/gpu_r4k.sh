@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: the weight-stationary GEMM as BertIntermediate.dense inside the step (GELU epilogue), per-kernel times at C2 / C3 / C5
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out/r4k
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r4k
 L=$PWD/foldingdiff_amd/_lib
 {
 TAG=tile FDMI_GEMM_WS=0 timeout 200 python scripts/c3_times.py

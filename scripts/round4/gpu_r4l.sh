@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: the weight-stationary GEMM as the few-rows path -- full GPU suite, then small-batch step times with and without it
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out/r4l
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r4l
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r4l/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r4l/pytest_gpu.log
 tail -4 gpurun_out/r4l/pytest_gpu.log
 {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: q | k | v on the weight-stationary kernel -- bit identity at model level, the GPU suite, small-batch step times
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out/r4m
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r4m
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "few_rows or ws_bit or head_sizes or arbitrary_masks" > gpurun_out/r4m/pytest_ws.log 2>&1; echo "rc=$?" >> gpurun_out/r4m/pytest_ws.log
 tail -5 gpurun_out/r4m/pytest_ws.log
 {
