@@ -150,6 +150,12 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
 #ifndef FDMI_ATTN_ILP
 #define FDMI_ATTN_ILP 0  // (measured: no gain, profiles/r04_attention_ab4.log)  S^T tiles in pairs and band tiles 0 / 1 together: two independent accumulators alternate on the matrix pipe
 #endif
+#ifndef FDMI_ATTN_SNEXT
+#define FDMI_ATTN_SNEXT 0  // (measured: 11 % SLOWER, profiles/r04_attention_ab5_snext.log)  1: the S^T tiles of position p + 1 are multiplied at
+                           // the END of position p (behind barrier [D], in registers that are free since P V) instead of in front of
+                           // the band operations of p + 1.  The stamps of one group had suggested it: 7.0 k cycles in H1 against 4.3 k of
+                           // work in H2 -- but the third of H2 behind [D] (V copy issue, ctx pack + store) is no slack
+#endif
 #ifndef FDMI_ATTN_VLATE
 #define FDMI_ATTN_VLATE 0  // 1: the V copy and the ctx store wait for barrier [A] of the next position (H1) instead of running behind [D]
 #endif
@@ -364,6 +370,49 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     }
     pend = false;
   };
+  constexpr bool S_NEXT = FDMI_ATTN_SNEXT != 0;
+  f32x16 sacc[T];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // S^T tiles of the position whose K is in LDS and whose Q is in qh / ql: rows = keys r0 + 32 t + rowmap(r, half), cols = queries
+  // l0 + l31; raw MFMA sums (scale q_scale * k_scale).  tl_s = the position's live 32-key tiles.
+  // Two tiles at a time (FDMI_ATTN_ILP): their accumulators alternate on the matrix pipe
+  auto s_tiles = [&](int tl_s) {
+    auto kfrag = [&](int t, int c, f16x8& kh, f16x8& kl) {
+      // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
+      const unsigned char* pc = (FDMI_ATTN_DBG & 2) ? Ks + t * 4096 + lane * 16 : Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
+      const int ksz = (FDMI_ATTN_DBG & 2) ? 0 : (l31 >> 3) & 1;
+      kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
+      kl = *reinterpret_cast<const f16x8*>(pc + (((4 + 2 * c + half) ^ ksz) << 7));
+    };
+#pragma unroll
+    for (int t = 0; t < T; t += (FDMI_ATTN_ILP != 0 ? 2 : 1)) {
+      if (t >= tl_s) continue;
+      if (FDMI_ATTN_ILP != 0 && t + 1 < T && t + 1 < tl_s) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f16x8 kh0, kl0, kh1, kl1;
+          kfrag(t, c, kh0, kl0);
+          kfrag(t + 1, c, kh1, kl1);
+          // (the first product starts from the inline constant 0: no accumulator zeroing pass)
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
+          sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[c], c == 0 ? zero16 : sacc[t + 1], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[c], sacc[t], 0, 0, 0);
+          sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[c], sacc[t + 1], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[c], sacc[t], 0, 0, 0);
+          sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[c], sacc[t + 1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f16x8 kh, kl;
+          kfrag(t, c, kh, kl);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+        }
+      }
+    }
+  };
   if constexpr (STAG) {
     if (grp == 1) {  // (its copies of the distance table must have landed before group 0 reads the table behind this barrier)
       FD_WAIT_VM(G::VW);
@@ -411,9 +460,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       }
     }
 
-    f32x16 sacc[T];
     f32x16 racc[2];
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // ---- relative_key band.  Band origin of this wave's row block: band index x of the position <-> table row
     //   m = (maxpos-1) - (LP-1) + LP (qg-kt) + 32 wq + x,  x = 32 q + (row of tile q); S^T tile t element (key kl, query ql) needs
     //   x = 32 (T-1-t) + ql - kl + 31.  Rows outside the table (clamped) are only ever paired with padding keys / queries (L <= maxpos).
@@ -582,43 +629,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       });
     };
     if (compute) {
-      // S^T tiles: rows = keys r0 + 32 t + rowmap(r, half), cols = queries l0 + l31; raw MFMA sums (scale q_scale * k_scale).
-      // Two tiles at a time (FDMI_ATTN_ILP): their accumulators alternate on the matrix pipe
-      auto kfrag = [&](int t, int c, f16x8& kh, f16x8& kl) {
-        // key 32 t + l31: piece 4 t + l31 / 8, unit u at position u ^ (piece & 1)
-        const unsigned char* pc = (FDMI_ATTN_DBG & 2) ? Ks + t * 4096 + lane * 16 : Ks + (size_t)(4 * t + (l31 >> 3)) * 1024 + (l31 & 7) * 16;
-        const int ksz = (FDMI_ATTN_DBG & 2) ? 0 : (l31 >> 3) & 1;
-        kh = *reinterpret_cast<const f16x8*>(pc + (((2 * c + half) ^ ksz) << 7));
-        kl = *reinterpret_cast<const f16x8*>(pc + (((4 + 2 * c + half) ^ ksz) << 7));
-      };
-#pragma unroll
-      for (int t = 0; t < T; t += (FDMI_ATTN_ILP != 0 ? 2 : 1)) {
-        if (t >= tl) continue;
-        if (FDMI_ATTN_ILP != 0 && t + 1 < T && t + 1 < tl) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            f16x8 kh0, kl0, kh1, kl1;
-            kfrag(t, c, kh0, kl0);
-            kfrag(t + 1, c, kh1, kl1);
-            // (the first product starts from the inline constant 0: no accumulator zeroing pass)
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
-            sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[c], c == 0 ? zero16 : sacc[t + 1], 0, 0, 0);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[c], sacc[t], 0, 0, 0);
-            sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[c], sacc[t + 1], 0, 0, 0);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[c], sacc[t], 0, 0, 0);
-            sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[c], sacc[t + 1], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            f16x8 kh, kl;
-            kfrag(t, c, kh, kl);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
-          }
-        }
-      }
+      if (!S_NEXT || iter == 0) s_tiles(tl);  // (S_NEXT: done at the end of the previous position, except for the stream's first)
       if constexpr (REL) band_ops(IC<0>{}, IC<BP1>{});
     }
 
@@ -744,6 +755,7 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
     // ---- [D] every wave is done with V: copy the next position's V (V_LATE: behind barrier [A] of the next position)
     FD_STAMP(7);
     ++slot;
+    if (S_NEXT) FD_WAIT_VM(0);  // K(p+1) (+ Q) landed -- requested behind [B], a softmax and a P V product ago; nothing else is in flight
     barrier_keep_vm();
     if (!V_LATE && !(FDMI_ATTN_DBG & 64)) issue_v(nxt);
 
@@ -757,6 +769,13 @@ __global__ __launch_bounds__(256 * NG) void attn_img_kernel(AttnImgArgs p) {
       pend_voff = ok ? (unsigned)((((row >> 5) * H * 8 + 2 * half) * 32 + (row & 31)) * 16) : 0xFFFFFF00u;
       pend_hoff = h * 4096;  // block h of the row: (.. * H + h) * 8 units * 32 rows * 16 B
       if constexpr (!V_LATE) flush_ctx();
+    }
+    if (S_NEXT && !done) {
+      // S^T of the next position: its K is in LDS behind [D], its Q in qh / ql since [B], and the score registers are free since P V
+      const int nrows_n = p.seq_row0[nxt.b + 1] - p.seq_row0[nxt.b];
+      int tl_n = (p.nrow[nxt.b] - nxt.kt * LP + 31) >> 5;
+      tl_n = tl_n < 1 ? 1 : (tl_n > T ? T : tl_n);
+      if (wq < T && nxt.qg * LP + 32 * wq < nrows_n && !(FDMI_ATTN_DBG & 32)) s_tiles(tl_n);
     }
     if (!done) {
       cur = nxt;
