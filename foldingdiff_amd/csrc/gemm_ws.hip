@@ -383,6 +383,7 @@ static void launch(const GemmImgArgs& p, hipStream_t s) {
 // true if this shape runs on the weight-stationary kernel (K = 384, N a multiple of 32, column-local epilogue, image output)
 bool gemm_ws_supported(int epilogue, const GemmImgArgs& p) {
   if (p.K != 32 * ws::NKT || p.N % 32 != 0) return false;
+  if ((p.N + ws::SLICE - 1) / ws::SLICE > ws::n_cu() / 8) return false;  // an XCD's workgroups must hold at least one stream of slices
   if (epilogue == EPI_IMG_QKV) return p.N == 96 * p.H && p.LTOT % 32 == 0;  // q | k | v of head size 32 in one launch
   return (epilogue == EPI_IMG_GELU || epilogue == EPI_IMG_BIAS) && p.out_f32 == nullptr && p.resid == nullptr;
 }
