@@ -488,3 +488,36 @@ def test_gemm_tile_list_with_tail_slices():
                 g_main = max(nfull * nk - 2, 0) if sliced else G         # iteration g issues A(g + 2)
                 assert all((g + 2) // nk < nfull or not sliced for g in range(g_main))
             assert len(seen) == 4 * ntiles, (ntiles, grid, tail, len(seen))
+
+
+def test_weight_stationary_gemm_deals_every_group_to_every_slice_exactly_once():
+    """Index arithmetic of ws::gemm_ws_kernel (gemm_ws.hip), restated: workgroup b of 256 sits on XCD b % 8; an XCD's 32 workgroups
+    form S = 32 // nslice streams of nslice neighbours (workgroups beyond S * nslice idle); the XCD owns groups [NT x / 8, NT (x+1) / 8),
+    stream j takes every S-th of them; wave w of slice s owns column block 8 s + w.  Every (32-row group, 32-column block) of the
+    output must be produced exactly once, whatever the row count and for column counts that leave a slice partly empty."""
+    grid = 256
+    for N in (96, 128, 384, 768, 1152, 1280, 3072):
+        nb, nslice, per = N // 32, -(-N // 256), grid // 8
+        S = per // nslice
+        assert S >= 1
+        for NT in (1, 4, 7, 31, 64, 257, 984, 2048):   # rows / 32 (rows128 capacity: always a multiple of 4, odd ones for the arithmetic)
+            seen = {}
+            idle = 0
+            for b in range(grid):
+                xcd, jx = b & 7, b >> 3
+                if jx >= S * nslice:
+                    idle += 1
+                    continue
+                sl, j = jx % nslice, jx // nslice
+                tlo, thi = NT * xcd // 8, NT * (xcd + 1) // 8
+                cnt = (thi - tlo - j + S - 1) // S if tlo + j < thi else 0
+                for i in range(cnt):
+                    g = tlo + j + i * S
+                    assert tlo <= g < thi
+                    for w in range(8):
+                        cb = sl * 8 + w
+                        if cb < nb:
+                            assert (g, cb) not in seen, (N, NT, g, cb)
+                            seen[(g, cb)] = b
+            assert len(seen) == NT * nb, (N, NT, len(seen))
+            assert idle == 8 * (per - S * nslice)
