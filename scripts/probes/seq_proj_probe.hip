@@ -27,8 +27,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
 }
 
-// W: [head][k-tile][96 rows][128 B] (hi units 0-3, lo units 4-7 of 8 halves each), H: [sequence][4 row blocks][12 k-tiles][8 units][32 rows][16 B]
-template <int KPS, bool SCHED>  // k-tiles per ring stage (= per barrier); SCHED: operand reads interleaved with the MFMAs by decree
+// W: [head][k-tile][8 units: hi 0-3, lo 4-7][96 rows][16 B], H: [sequence][4 row blocks][12 k-tiles][8 units][32 rows][16 B]
+template <int KPS, bool SCHED, bool LATE = false>  // k-tiles per ring stage (= per barrier); SCHED: operand reads interleaved with the MFMAs by decree; LATE: the copies of stage + 3 are issued behind the stage's MFMAs instead of in front
 __global__ __launch_bounds__(256) void seq_proj_kernel(const unsigned char* W, const unsigned char* Himg, float* out, int nseq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = KPS * KT_BYTES;
@@ -67,22 +67,25 @@ __global__ __launch_bounds__(256) void seq_proj_kernel(const unsigned char* W, c
         const int pos = head * (NKT / KPS) + sg;
         __builtin_amdgcn_s_waitcnt(0x0F70 | ((6 * KPS) & 15) | (((6 * KPS) >> 4) << 14));  // vmcnt(6 KPS): this stage landed (two younger in flight)
         __builtin_amdgcn_s_barrier();
-        issue(pos + 3);
+        if (!LATE) issue(pos + 3);
 #pragma unroll
         for (int kk = 0; kk < KPS; ++kk) {
           const int kt = sg * KPS + kk;
-          const unsigned char* st = smem + (pos % NST) * STAGE + kk * KT_BYTES + l31 * 128 + half * 16;
+          // stage layout UNIT-MAJOR: [unit 0-7][96 rows][16 B] -- a half-wave reads 32 consecutive 16-byte slots (row-major rows of
+          // 128 B put every other row on the same banks: the first version of this probe measured 8-way conflicts, not the design)
+          const unsigned char* st = smem + (pos % NST) * STAGE + kk * KT_BYTES + l31 * 16;
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              const f16x8 wh = *reinterpret_cast<const f16x8*>(st + j * 4096 + c * 32);
-              const f16x8 wl = *reinterpret_cast<const f16x8*>(st + j * 4096 + 64 + c * 32);
+              const f16x8 wh = *reinterpret_cast<const f16x8*>(st + (2 * c + half) * 1536 + j * 512);
+              const f16x8 wl = *reinterpret_cast<const f16x8*>(st + (4 + 2 * c + half) * 1536 + j * 512);
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[kt][c], acc[j], 0, 0, 0);
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[kt][c], acc[j], 0, 0, 0);
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[kt][c], acc[j], 0, 0, 0);
             }
         }
+        if (LATE) issue(pos + 3);
         if constexpr (SCHED) {  // 12 KPS operand reads, 18 KPS MFMAs: four reads up front, then two reads behind every three MFMAs
           __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -151,5 +154,8 @@ int main() {
   run(seq_proj_kernel<2, false>, 2, 0);
   run(seq_proj_kernel<2, true>, 2, 1);
   run(seq_proj_kernel<3, true>, 3, 1);
+  printf("  copies issued behind the stage's MFMAs:\n");
+  run(seq_proj_kernel<1, true, true>, 1, 1);
+  run(seq_proj_kernel<2, true, true>, 2, 1);
   return 0;
 }
