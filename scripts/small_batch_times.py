@@ -19,7 +19,7 @@ model = modelling.BertForDiffusionBase(modelling.BertConfig(**RELEASED), [True] 
 betas = beta_schedules.cosine_beta_schedule(1000)
 model.prepare(betas)
 tag = os.environ.get("TAG", "")
-for B in (1, 4, 8, 16, 32, 64, 96, 128):
+for B in [int(b) for b in os.environ.get("BATCHES", "1,4,8,16,32,64,96,128").split(",")]:
     x = torch.randn(B, 128, 6, device="cuda:0")
     lens = torch.full((B,), 128, dtype=torch.int32, device="cuda:0")
     sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=3)
