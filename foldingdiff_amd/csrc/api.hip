@@ -54,6 +54,7 @@ struct LayerDev {
   // row-image path: weight images padded to 384 rows, and the (static, power-of-two) scales of this layer's
   // activation images -- derived from norm bounds of the weights at fd_finalize, so nothing can overflow fp16
   SplitW wqk_i, wv_i, wqkv_i, wo_i, wi_i, wd_i;  // wqkv_i: q | k | v rows in one image (n_heads % 6 == 0: one launch)
+  SplitW wsa_i;  // the same q | k | v weights ordered per head for the fused projection + attention kernel (seq_attn.hip), or null
   float *bqk = nullptr, *bv = nullptr;  // bias slices of bqkv
   float s_h = 1.f, s_q = 1.f, s_k = 1.f, s_v = 1.f, s_a = 1.f, s_g = 1.f;
   float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
@@ -63,11 +64,11 @@ struct LayerDev {
 
 enum KClass {
   KC_EMBED = 0, KC_GEMM_QKV, KC_GEMM_V, KC_ATTN, KC_GEMM_OUT, KC_LN1, KC_GEMM_UP, KC_GEMM_DOWN, KC_LN2, KC_GEMM_HEAD,
-  KC_HEAD_UPDATE, KC_ADVANCE, KC_COUNT
+  KC_HEAD_UPDATE, KC_ADVANCE, KC_SEQ_ATTN, KC_COUNT
 };
 const char* const kClassName[KC_COUNT] = {
     "embed_ln_time", "gemm_qkv", "gemm_v", "attention", "gemm_attn_out", "layernorm_attn", "gemm_ffn_up",
-    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance"};
+    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance", "qkv_attention_fused"};
 
 struct Workspace {
   int B = 0, L = 0;
@@ -88,6 +89,7 @@ struct Workspace {
   hipGraphExec_t graph = nullptr;
   int graph_fuse_ln = -2;  // option value the graph was captured with (-2: none)
   int graph_varlen = -1;   // ... and the row mode (packed rows launch the slice-capable GEMM instantiation)
+  int graph_fuse_attn = -2;  // ... and the fused projection + attention choice
   uint64_t last_use = 0;
   void release() {
     if (graph) (void)hipGraphExecDestroy(graph);
@@ -100,6 +102,8 @@ struct Workspace {
     *this = Workspace();
   }
 };
+
+constexpr long long kStampWords = 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16;
 
 struct PendingEvent {
   int cls;
@@ -129,11 +133,13 @@ struct fd_model {
   // options
   int fuse_ln = -1;  // -1 auto: LN-fused GEMMs with fp16x3 (measured 9.37 vs 10.15 ms/step), not with fp32 (slower there)
   int use_graph = 1;
-  unsigned long long* stamps = nullptr;  // debug cycle stamps (FDMI_STAMPS=1): gemm [5][8][64][6] then attention [4][64][8]
+  unsigned long long* stamps = nullptr;  // debug cycle stamps (FDMI_STAMPS=1): gemm [5][8][64][6], attention [4][64][8], fused attention [4][64][16]
   int debug_stop = 0;  // row-image path: stop a step after this many launches (debug dumps; 0 = off)
   int debug_layer = 0; // layer whose scales fd_debug_read uses
   int split_qkv = 0; // row-image path: 1 = q | k and v^T as two launches even when one would do (A/B, tests)
   int varlen = 0;    // row-image path: only the first lens[b] positions of a sequence are token rows
+  int fuse_attn = -1;  // row-image path: q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): -1 auto (padded rows of
+                     // 97 .. 128 positions), 0 never, 1 wherever the kernel applies (packed rows too)
   // workspaces (buffers + captured graph) are kept per (B, L): sample_length()-driven sampling and ragged chunks
   // alternate between a few shapes
   std::vector<Workspace> cache;
@@ -218,6 +224,31 @@ int upload_split(fd_model* m, SplitW* dst, const float* W, int N, int K, int row
   std::vector<uint16_t> img;
   if (row_pad == 384) pack_weight_tiles(W, N, K, &img, &dst->scale);
   else pack_split_weight(W, N, K, &img, &dst->scale, row_pad);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, img.size() * 2));
+  m->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  dst->p = p;
+  return FD_OK;
+}
+
+// seq_attn.hip's weights: the q | k | v projection [3 d][d] ordered per head, [head][k-tile][unit 0-7][96 rows: q_h | k_h | v_h][16 B]
+// (a k-tile of a head = one 12 KiB LDS ring stage, byte for byte, unit-major), split at the SAME scale as wqkv_i (one power of two for
+// the whole matrix), so the fused kernel multiplies the very same fp16 hi / lo values as the tile GEMM.
+int upload_seq_attn_weights(fd_model* m, SplitW* dst, const float* W, int d) {
+  std::vector<uint16_t> rm, img;
+  pack_split_weight(W, 3 * d, d, &rm, &dst->scale, 384);
+  const int nk = d / 32, H = d / 32;
+  img.assign((size_t)H * nk * 96 * 64, 0);
+  for (int h = 0; h < H; ++h)
+    for (int kt = 0; kt < nk; ++kt) {
+      uint16_t* stage = img.data() + ((size_t)h * nk + kt) * 96 * 64;
+      for (int r = 0; r < 96; ++r) {
+        const int n = (r / 32) * d + h * 32 + (r % 32);
+        const uint16_t* blk = rm.data() + ((size_t)n * nk + kt) * 64;
+        for (int u = 0; u < 8; ++u) memcpy(stage + ((size_t)u * 96 + r) * 8, blk + u * 8, 16);
+      }
+    }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, img.size() * 2));
   m->allocs.push_back(p);
@@ -364,6 +395,8 @@ int ensure_ws(fd_model* m, int B, int L) {
     fl[KC_GEMM_HEAD] = 2 * Md * dd * dd;       by[KC_GEMM_HEAD] = 4 * (2 * Md * dd + dd * dd);
     fl[KC_HEAD_UPDATE] = 2 * Md * dd * F;      by[KC_HEAD_UPDATE] = 4 * (Md * dd + 3 * Md * F);
     fl[KC_ADVANCE] = 0;                        by[KC_ADVANCE] = 4;
+    // fused q | k | v projection + attention: h in, ctx out, the weights once (q, k, v stay on chip)
+    fl[KC_SEQ_ATTN] = 2 * Md * 3 * dd * dd + 6 * Ld * dd * Md;  by[KC_SEQ_ATTN] = 4 * (2 * Md * dd + 3 * dd * dd);
   }
   w.last_use = ++m->use_clock;
   if (w.B == B && w.L == L) return FD_OK;
@@ -637,8 +670,8 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
   }
   static const bool want_stamps = [] { const char* e = getenv("FDMI_STAMPS"); return e && atoi(e) != 0; }();
   if (want_stamps && !m->stamps) {
-    HIP_TRY(hipMalloc((void**)&m->stamps, (5 * 8 * 64 * 6 + 4 * 64 * 8) * 8));
-    HIP_TRY(hipMemset(m->stamps, 0, (5 * 8 * 64 * 6 + 4 * 64 * 8) * 8));
+    HIP_TRY(hipMalloc((void**)&m->stamps, kStampWords * 8));
+    HIP_TRY(hipMemset(m->stamps, 0, kStampWords * 8));
   }
   // do the tiles of an N-column GEMM over this workspace fill whole rounds of the launch's workgroups?  Padded rows: the row count
   // is the workspace's capacity, known here; packed rows (sampling.sample): data dependent -> the slice-capable instantiation
@@ -660,7 +693,27 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
   for (int li = 0; li < c.n_layers; ++li) {
     const LayerDev& lw = m->layers[li];
     const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
-    if (lw.wqkv_i.p && !m->split_qkv) {
+    // q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): q, k and v never reach HBM
+    static const int fuse_attn_env = [] { const char* e = getenv("FDMI_FUSE_ATTN"); return e ? atoi(e) : -1; }();
+    const int fuse_attn = m->fuse_attn >= 0 ? m->fuse_attn : fuse_attn_env;
+    const bool fused_attn = lw.wsa_i.p && fuse_attn > 0 /* (auto: off until the kernel beats the two-kernel path) */ && !mode.kmask && !m->split_qkv &&
+                            seq_attn_supported(d, c.n_heads, L, c.max_pos) && (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
+    if (fused_attn) {
+      SeqAttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.himg = w.himg; a.himg_bytes = (unsigned)((size_t)w.cap * d * 4);
+      a.wimg = static_cast<const unsigned char*>(lw.wsa_i.p); a.bias = lw.bqkv;
+      a.demb = static_cast<const u32x4_t*>(lw.demb_s.p);
+      a.lens = w.lens; a.nrow = w.nrow; a.seq_row0 = w.seq_row0; a.ctx = w.cimg;
+      a.B = B; a.H = H; a.maxpos = c.max_pos;
+      a.acc_scale = 1.0f / (lw.s_h * lw.wsa_i.scale);
+      a.q_scale = lw.s_q; a.k_scale = lw.s_k; a.v_scale = lw.s_v; a.ctx_scale = lw.s_v;
+      a.r_scale = lw.s_k / lw.demb_s.scale;
+      a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 + 4 * 64 * 8 : nullptr;
+      PROF(KC_SEQ_ATTN, launch_seq_attn(a, s));
+      DBG_STOP();
+      DBG_STOP();  // (two launches of the other path: debug_stop counts stay comparable)
+    } else if (lw.wqkv_i.p && !m->split_qkv) {
       // q | k | v in one launch: the three column tiles of a row panel run side by side on one XCD (h is read from HBM once)
       GemmImgArgs g = base();
       g.A = w.himg; g.W = static_cast<const unsigned char*>(lw.wqkv_i.p); g.bias = lw.bqkv;
@@ -689,7 +742,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
         DBG_STOP();
       }
     }
-    {
+    if (!fused_attn) {
       AttnImgArgs a;
       memset(&a, 0, sizeof a);
       a.qbuf = w.qbuf; a.kbuf = w.kbuf; a.vbuf = w.vbuf;
@@ -838,7 +891,7 @@ int check_lens(const int32_t* lens, int B, int L) {
 
 int ensure_graph(fd_model* m) {
   Workspace& w = m->ws;
-  if (w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
+  if (w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
   if (w.graph) {
     (void)hipGraphExecDestroy(w.graph);
     w.graph = nullptr;
@@ -868,6 +921,7 @@ int ensure_graph(fd_model* m) {
   if (e != hipSuccess) return fail(FD_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   w.graph_fuse_ln = m->fuse_ln;
   w.graph_varlen = m->varlen;
+  w.graph_fuse_attn = m->fuse_attn;
   return FD_OK;
 }
 
@@ -1194,6 +1248,9 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
       if (int rc = upload_split(m, &lw.wv_i, wqkv.data() + 2 * d * d, (int)d, (int)d, 384)) return rc;
       if (sub_heads(c) % 6 == 0)
         if (int rc = upload_split(m, &lw.wqkv_i, wqkv.data(), 3 * (int)d, (int)d, 384)) return rc;
+      lw.wsa_i = SplitW();
+      if (c.pos_type == FD_POS_RELATIVE_KEY && seq_attn_supported((int)d, c.n_heads, c.max_pos < 128 ? c.max_pos : 128, c.max_pos))
+        if (int rc = upload_seq_attn_weights(m, &lw.wsa_i, wqkv.data(), (int)d)) return rc;
       lw.bqk = lw.bqkv;
       lw.bv = lw.bqkv + 2 * d;
       lw.s_h = scale_for(hb.linf);
@@ -1283,6 +1340,7 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   if (n == "fuse_ln") m->fuse_ln = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
   else if (n == "varlen") m->varlen = value ? 1 : 0;
+  else if (n == "fuse_attn") m->fuse_attn = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "split_qkv") {
     m->split_qkv = value ? 1 : 0;
     drop_workspaces(m);  // captured graphs hold the other launch sequence
@@ -1833,7 +1891,7 @@ int fd_debug_read(fd_model* m, const char* name, float* out, int64_t n_floats) {
   else if (nm == "k") rc = qkv(w.kbuf, 128, 2, lw.s_k);
   else if (nm == "v") rc = qkv(w.vbuf, 0, 1, lw.s_v);
   else if (nm == "stamps") {
-    need = 5 * 8 * 64 * 6 + 4 * 64 * 8;
+    need = n_floats >= 2 * kStampWords ? kStampWords : 5 * 8 * 64 * 6 + 4 * 64 * 8;  // (older scripts ask for the first two tables only)
     if (n_floats < 2 * need) return fail(FD_E_INVALID, "fd_debug_read(stamps): need %lld floats (uint64 view)", 2 * need);
     if (!m->stamps) return fail(FD_E_STATE, "no stamps were recorded (FDMI_STAMPS=1)");
     HIP_TRY(hipMemcpy(out, m->stamps, need * 8, hipMemcpyDeviceToHost));

@@ -171,6 +171,27 @@ bool launch_attention_img(const AttnImgArgs& p, int L, hipStream_t s);
 // head sizes 32 * nb, nb = 1 .. 4 (attention_gen.hip; nb = 1 only for arbitrary key masks, which the tuned kernel does not take): p.H = heads; qbuf / kbuf / vbuf / ctx / demb are indexed by 32-column sub-head
 bool launch_attention_gen(const AttnImgArgs& p, int nb, hipStream_t s);
 
+// seq_attn.hip: BertSelfAttention's q | k | v projection AND the attention of a whole sequence in ONE kernel (L <= 128, head size 32,
+// relative_key, maxpos <= 128): q, k and v never reach HBM.  One 4-wave workgroup per sequence; the hidden state stays in registers.
+struct SeqAttnArgs {
+  const unsigned char* himg;   // hidden-state image [rows128][d/32] (grouped, img_common.h)
+  unsigned himg_bytes;         // its size (< 4 GiB: 32-bit lane offsets; rows beyond it read as zeros)
+  const unsigned char* wimg;   // weight image [head][k-tile][unit 0-7][96 rows: q_h | k_h | v_h][16 B] at the scale of wqkv_i (api.hip: pack_seq_attn_weights)
+  const float* bias;           // [3 d]: q | k | v
+  const u32x4_t* demb;         // distance table image [2 maxpos - 1][128 B]
+  const int* lens;             // [B] unmasked keys per sequence
+  const int* nrow;             // [B] positions that are rows at all
+  const int* seq_row0;         // [B + 1] first token row of each sequence
+  unsigned char* ctx;          // image [rows128][H][128 B]
+  int B, H, maxpos;
+  float acc_scale;             // 1 / (scale of himg * scale of wimg)
+  float q_scale, k_scale, v_scale, ctx_scale;
+  float r_scale;               // k_scale / scale of the distance table
+  unsigned long long* stamps;  // null, or [4 waves][64 slots][16] cycle stamps of workgroup 0 (debug)
+};
+bool seq_attn_supported(int d_model, int n_heads, int L, int maxpos);
+void launch_seq_attn(const SeqAttnArgs& p, hipStream_t s);
+
 struct EmbedImgArgs {
   const float* x;              // [B][L][F]
   const float* w_in; const float* b_in; const float* pos_emb; const float* gamma; const float* beta;

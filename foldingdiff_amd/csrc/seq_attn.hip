@@ -1,0 +1,707 @@
+// BertSelfAttention of a whole sequence in ONE kernel: the q | k | v projection (HF 4.11.3 BertSelfAttention.query / key / value,
+// constructed at foldingdiff/modelling.py:271, called :473-480) AND the attention with the relative_key term, the additive -10000
+// key mask and the softmax -- q, k and v never reach HBM (the two-kernel path writes 302 MB of them per layer at BASELINE C2 and
+// reads them back: 37 % of a step's stored bytes).
+//
+// Arithmetic: the same fp16 hi / lo split triples on v_mfma_f32_32x32x16_f16, in the same order per accumulator, as gemm_img.hip
+// (projection) and attention_img.hip (S^T = K Q^T, the band R^T = E Q^T, O^T = V^T P^T); the ctx image this kernel writes is
+// BIT-IDENTICAL to the one the two kernels write (tests/test_gpu_parity.py).
+//
+// Structure.  One 4-wave workgroup (one wave per SIMD, 512 registers each) per CU, persistent over sequences of <= 128 rows:
+//  * wave w owns token rows 32 w .. 32 w + 31 of the sequence; its rows of the hidden state (K = 384: 12 k-tiles x 2 k16 steps x
+//    (hi, lo) x 4 registers = 192 registers) are loaded ONCE per sequence and stay in registers as MFMA operands (B operand of the
+//    swapped form D^T = W h^T for q and k: a lane owns a token; A operand of the normal form for v: a lane owns a feature, which is
+//    what O^T = V^T P^T wants);
+//  * the weights stream head by head through an LDS ring: a stage = one k-tile of a head's 96 rows (q_h | k_h | v_h), 12 KiB,
+//    unit-major ([unit][96 rows][16 B]: conflict-free 16-byte fragment reads), copied by LDS-DMA three pieces per wave, ring of 4,
+//    ONE workgroup barrier per stage;
+//  * per head the epilogue turns the three 32 x 32 accumulators into: q_h -> this wave's B operand registers (bias, scale, hi / lo
+//    split, one half-wave exchange); k_h -> LDS in the attention kernel's unit-major piece layout; v_h -> LDS as V^T blocks;
+//  * the attention of head h-1 is SOFTWARE PIPELINED into the twelve stages of head h's projection (slices, see attn_slice): with
+//    one wave per SIMD there is no partner wave to hide a dependent chain behind (S^T -> band -> softmax -> P V -> store), so every
+//    link of that chain sits one stage (~1000 cycles) behind the previous one and the matrix instructions of the projection fill
+//    the softmax / skew arithmetic's issue slots (plain fp32 VALU issues beside the matrix pipe: this file is compiled with
+//    -fno-slp-vectorize).  A sequence is 13 iterations: projection of head 0 alone, 11 fused ones, attention of head 11 alone
+//    (during which the next sequence's hidden state is fetched).
+// Wave-uniform branches inside the fused iteration would split the stage into separately scheduled blocks, so every wave always
+// computes all 128 query / key rows: rows beyond the sequence's rows are finite garbage whose keys get -inf scores (probability
+// exactly 0) and whose ctx stores fall outside the buffer descriptor (dropped by the hardware).
+#include <cstdlib>
+#include <type_traits>
+
+#include "fdmi_kernels.h"
+#include "img_common.h"
+
+#ifndef FDMI_SA_SCHED
+#define FDMI_SA_SCHED 1  // 1: the stage's instruction order is dictated with sched_group_barrier (MFMA : LDS read : VALU pattern)
+#endif
+#ifndef FDMI_SA_DBG
+#define FDMI_SA_DBG 0  // ablation builds (wrong results): 1 = no attention slices, 2 = no projection MFMAs, 4 = no ctx stores
+#endif
+
+namespace fdmi {
+namespace sa {
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(IC<LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
+typedef const __attribute__((address_space(3))) float* lds_cf32_t;
+typedef const __attribute__((address_space(3))) u32x4* lds_cu128_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(lds_ptr_t)(const_cast<void*>(p)); }
+__device__ __forceinline__ float lds_f32(unsigned a) { return *(lds_cf32_t)(unsigned long long)a; }
+__device__ __forceinline__ u32x4 lds_u128(unsigned a) { return *(lds_cu128_t)(unsigned long long)a; }
+
+constexpr float PS = 1024.0f;  // probabilities are <= 1
+constexpr float kLog2e = 1.44269504088896341f;
+constexpr float kInvSqrtD = 0.17677669529663687f;  // 1 / sqrt(32)
+
+__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ void pair_halves(float x, float& lo, float& hi) {  // (attention_img.hip)
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  swap32(a, b);
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float pair_max(float x) {
+  float lo, hi;
+  pair_halves(x, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  float lo, hi;
+  pair_halves(x, lo, hi);
+  return lo + hi;
+}
+
+// One int of a small device table as a SCALAR load, complete on return.  Inside the item loop hipcc reads such tables with
+// global_load_dword (the kernel also stores, so the tables are not provably invariant), and the vmcnt(0) it then puts in front of the
+// first use drains the weight stream.
+__device__ __forceinline__ int sload(const int* base, int index) {
+  int v;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(index * 4) : "memory");
+  return v;
+}
+
+constexpr int T = 4, LP = 128;          // key tiles of 32, keys per sequence tile
+constexpr int NST = 4;                  // weight ring stages
+constexpr int KT_BYTES = 96 * 128;      // one k-tile of a head's 96 weight rows
+constexpr int OFF_E = 0;                // distance table image, 256 rows x 128 B
+constexpr int OFF_K = 32768;            // K of the current head: 128 keys x 128 B, unit-major pieces
+constexpr int OFF_V = OFF_K + 16384;    // V^T of the current head: 4 key blocks x 32 d x 128 B
+constexpr int OFF_R = OFF_V + 16384;    // skew scratch: 4 waves x two 4 KiB tile slots
+constexpr int OFF_W = OFF_R + 32768;    // weight ring
+constexpr int OFF_B = OFF_W + NST * KT_BYTES;  // bias q | k | v at the images' scales, 3 x 384 floats
+constexpr int SMEM = OFF_B + 3 * 384 * 4;      // 152,064 B
+
+// The relative_key band as operations on band tiles (attention_img.hip: band_op): M(q) R^T tile q = E_q Q^T into accumulator q & 1,
+// W(q) accumulator -> scratch slot q & 1, G(q) S^T tile T-1-q += band values of the tile pair (q, q+1).  Program order
+//     M0 M1 W0 W1 | M2 G0 W2 | M3 G1 W3 | M4 G2 W4 | G3        (one group per attention slice)
+
+template <int NKT, bool PROF>
+__global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
+  static_assert(NKT == 12 || NKT == 6, "d_model 384 or 192");
+  constexpr int H = NKT;              // heads of size 32
+  constexpr int SPS = 12 / NKT;       // attention slices per projection stage
+  constexpr int D = 32 * NKT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned char* Es = smem + OFF_E;
+  unsigned char* Ks = smem + OFF_K;
+  unsigned char* Vt = smem + OFF_V;
+  unsigned char* Rw = smem + OFF_R + wq * 8192;
+  unsigned char* Wr = smem + OFF_W;
+  float* par = reinterpret_cast<float*>(smem + OFF_B);
+  const unsigned rw_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)(Rw));
+
+  // ---- once per workgroup: bias at the scale of the image its column feeds ((acc os + b) sc == fma(acc, os sc, b sc) exactly for the
+  // power-of-two sc: gemm_img.hip), the distance table (attention_img.hip, ELDS: LDS row rho holds table row clamp(rho - esh))
+  for (int i = tid; i < 3 * D; i += 256) {
+    const float sc = i < D ? p.q_scale : (i < 2 * D ? p.k_scale : p.v_scale);
+    par[i] = p.bias[i] * sc;
+  }
+  const int esh = LP > p.maxpos ? LP - p.maxpos : 0;
+  {
+    const int nrow_e = 2 * p.maxpos - 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.demb)), 0, nrow_e * 128, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int piece = wq + 4 * i;  // LDS rows 8 piece .. 8 piece + 7
+      const int rho = 8 * piece + (lane >> 3);
+      int row = rho - esh;
+      row = row < 0 ? 0 : (row > nrow_e - 1 ? nrow_e - 1 : row);
+      dma16(rs, (lds_ptr_t)(Es) + piece * 1024, row * 128 + (((lane & 7) ^ ((rho >> 1) & 7)) << 4), 0);
+    }
+  }
+  // band geometry of this lane (attention_img.hip): MFMA row i of a band tile computes band row pi(i)
+  const int pi31 = (l31 & 24) | ((l31 & 3) << 1) | ((l31 >> 2) & 1);
+  // gather addresses (attention_img.hip): query l31, key kl = kl_r + 4 half needs band index j = l31 - kl + 31 of its tile pair, byte
+  // j * 128 + 4 l31 of the pair's 63 consecutive band rows.  Even pairs have their lower tile in slot 0: address gb + (27 - kl_r) * 128,
+  // an immediate offset.  Odd pairs have the slots swapped (lower tile in slot 1): the same address + 4096, wrapped around the wave's
+  // 8 KiB scratch (which is 8 KiB aligned) -- one add and one and-or per score instead of a sixteen-register address table, which
+  // this kernel cannot afford (attention_img.hip keeps the table).
+  const unsigned gb = lds_addr(Rw) + (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31);
+  const unsigned gwrap = (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31) + 4096u;  // offset inside the scratch, before wrapping
+  const unsigned rw_base = lds_addr(Rw);
+  static_assert(OFF_R % 8192 == 0, "the skew scratch of a wave must be 8 KiB aligned");
+  unsigned eaddr[4];
+  {
+    const int rho0 = p.maxpos - LP + esh + 32 * wq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rp = rho0 + pi31;
+      eaddr[k] = lds_addr(Es) + (unsigned)(rp * 128 + (((2 * k + half) ^ ((rp >> 1) & 7)) << 4));
+      asm volatile("" : "+v"(eaddr[k]));
+    }
+  }
+  // K / V addresses of this lane: key (row) 32 wq + l31 of the head's K tile, feature row l31 of the V^T blocks
+  const int ksz = (l31 >> 3) & 1;
+  const unsigned k_rd = lds_addr(Ks) + (unsigned)((l31 >> 3) * 1024 + (l31 & 7) * 16);  // + 4096 t + ((unit ^ ksz) << 7)
+  const unsigned k_wr = k_rd + (unsigned)(wq * 4096);
+  const int vsz = vt_swz(l31);
+  const unsigned v_rd = lds_addr(Vt) + (unsigned)(l31 * 128);  // + 4096 t + ((unit ^ vsz) << 3)
+  const unsigned v_wr = v_rd + (unsigned)(wq * 4096);
+  const unsigned w_rd = lds_addr(Wr) + (unsigned)(l31 * 16 + half * 1536);  // + slot * KT_BYTES + (2 c + 4 plane) * 1536 + 512 j
+
+  const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
+  const float mask_raw = -10000.0f * kLog2e / s_scale;                  // (1 - mask) * -10000 at the raw scale (modelling.py:452)
+  const float oss_q = p.acc_scale * p.q_scale, oss_k = p.acc_scale * p.k_scale, oss_v = p.acc_scale * p.v_scale;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // ---- the weight stream: positions (sequence, head, k-tile) of this workgroup, one 12 KiB stage each; the stream does not stop at
+  // a sequence's end (the next sequence's first stages are requested during the last head)
+  const int nseq = (p.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = nseq * H * NKT;
+  int pos = 0;   // position being computed
+  int wsrc = 0;  // (head, k-tile) index of the next position to request, 0 .. H NKT - 1
+  int wreq = 0;  // positions requested so far
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.wimg), 0, H * NKT * KT_BYTES, 0x00020000);
+  auto issue_w = [&]() __attribute__((always_inline)) {  // past the end: the last position again (lands in a free slot, never read)
+    const lds_ptr_t dst = (lds_ptr_t)(Wr) + __builtin_amdgcn_readfirstlane((wreq & (NST - 1)) * KT_BYTES);
+    const int so = __builtin_amdgcn_readfirstlane(wsrc * KT_BYTES);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dma16(rs_w, dst + (wq + 4 * k) * 1024, lane * 16, so + (wq + 4 * k) * 1024);
+    ++wreq;
+    if (wreq < total) wsrc = wsrc + 1 == H * NKT ? 0 : wsrc + 1;
+  };
+
+  // ---- per-sequence state
+  f16x8 hh[NKT][2], hl[NKT][2];  // the wave's rows of the hidden state
+  f32x16 acc[3];                 // q_h | k_h (swapped form) | v_h (normal form) of the head being projected
+  f16x8 qh[2], ql[2];            // Q operand of the head whose attention is running
+  f32x16 sacc[T], racc[2], oacc;
+  float mt = 0.f, nm = 0.f, l_run = 1.f;
+  // the sequence of the head whose ATTENTION is running (one item behind the projection; nrows 0: every ctx store is dropped)
+  int row0 = 0, nrows = 0, Lb = LP, len = LP;
+
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.himg), 0, p.himg_bytes, 0x00020000);
+  // the lane's rows of k-tile kt of the hidden state of the sequence whose first row is r0 (rows beyond the image read as zeros)
+  auto load_h_kt = [&](auto KT, int r0) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value;
+    const int row = r0 + 32 * wq + l31;
+    const unsigned hoff = (unsigned)(((row >> 5) * (NKT * 256) + (row & 31)) * 16 + half * 512);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      hh[kt][c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, (int)hoff, (kt * 8 + 2 * c) * 512, 0));
+      hl[kt][c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, (int)hoff, (kt * 8 + 4 + 2 * c) * 512, 0));
+    }
+  };
+
+  const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
+  unsigned long long* st = PROF ? p.stamps + (size_t)wq * 64 * 16 : nullptr;
+  int slot = 0;
+#define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define FD_SB() __builtin_amdgcn_sched_barrier(0)
+
+  // ================================================================ projection: one stage = one k-tile of the head's 96 weight rows =
+  // six groups of three MFMAs (one per accumulator: consecutive MFMAs never share one; per accumulator the order of gemm_img.hip,
+  // wh ah | wh al | wl ah per k16 step).  Two fragment buffers: X = the hi plane of the step, Y = its lo plane; the next step's planes
+  // are requested right behind the last group that reads the buffer, i.e. at least one group (96 matrix cycles) + one attention chunk
+  // before their first use.
+  f16x8 Xw[3], Yw[3];
+  unsigned wb = 0;  // this lane's fragment base inside the stage being computed
+  auto rd_w = [&](f16x8 (&dst)[3], int unit) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dst[j] = __builtin_bit_cast(f16x8, lds_u128(wb + (unsigned)(unit * 1536 + j * 512)));
+  };
+  auto mm3 = [&](const f16x8 (&w)[3], const f16x8& hf) __attribute__((always_inline)) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], hf, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], hf, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf, w[2], acc[2], 0, 0, 0);  // v: normal form (lane = feature)
+  };
+  auto proj_top = [&]() __attribute__((always_inline)) {
+    wb = w_rd + (unsigned)((pos & (NST - 1)) * KT_BYTES);
+    rd_w(Xw, 0);
+    rd_w(Yw, 4);
+  };
+  auto proj_group = [&](auto KT, auto G) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value, g = decltype(G)::value;
+    if (FDMI_SA_DBG & 2) return;
+    if constexpr (g == 0) mm3(Xw, hh[kt][0]);
+    if constexpr (g == 1) { mm3(Xw, hl[kt][0]); rd_w(Xw, 2); }
+    if constexpr (g == 2) { mm3(Yw, hh[kt][0]); rd_w(Yw, 6); }
+    if constexpr (g == 3) mm3(Xw, hh[kt][1]);
+    if constexpr (g == 4) mm3(Xw, hl[kt][1]);
+    if constexpr (g == 5) mm3(Yw, hh[kt][1]);
+  };
+
+  // ---- the head's epilogue: q_h -> operand registers, k_h -> LDS (unit-major pieces), v_h -> LDS (V^T blocks); accumulators zeroed
+  auto split16 = [&](const float (&o)[16], unsigned (&Hh)[4][2], unsigned (&Lo)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) split_pair(o[4 * q + 2 * dd], o[4 * q + 2 * dd + 1], Hh[q][dd], Lo[q][dd]);
+  };
+  // quad layout (lane half h owns d = 8 q + 4 h + e) -> MFMA operand layout (lane half h owns units 2 c + h: d = 16 c + 8 h + 0..7):
+  // the half-waves exchange quad 1 of the lower against quad 0 of the upper lanes, and quad 3 against quad 2
+  auto quad_to_operand = [&](unsigned (&X)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      swap32(X[0][dd], X[1][dd]);
+      swap32(X[2][dd], X[3][dd]);
+    }
+  };
+  auto epilogue = [&](int head) __attribute__((always_inline)) {
+    {  // q
+      float o[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(par + head * 32 + 8 * q + 4 * half);
+        o[4 * q + 0] = __builtin_fmaf(acc[0][4 * q + 0], oss_q, b4.x);
+        o[4 * q + 1] = __builtin_fmaf(acc[0][4 * q + 1], oss_q, b4.y);
+        o[4 * q + 2] = __builtin_fmaf(acc[0][4 * q + 2], oss_q, b4.z);
+        o[4 * q + 3] = __builtin_fmaf(acc[0][4 * q + 3], oss_q, b4.w);
+      }
+      unsigned Hh[4][2], Lo[4][2];
+      split16(o, Hh, Lo);
+      quad_to_operand(Hh);
+      quad_to_operand(Lo);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        qh[c] = __builtin_bit_cast(f16x8, u32x4{Hh[2 * c][0], Hh[2 * c][1], Hh[2 * c + 1][0], Hh[2 * c + 1][1]});
+        ql[c] = __builtin_bit_cast(f16x8, u32x4{Lo[2 * c][0], Lo[2 * c][1], Lo[2 * c + 1][0], Lo[2 * c + 1][1]});
+      }
+    }
+    {  // k: this lane's key is row 32 wq + l31 of the K tile; unit u at position u ^ (piece & 1)
+      float o[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(par + D + head * 32 + 8 * q + 4 * half);
+        o[4 * q + 0] = __builtin_fmaf(acc[1][4 * q + 0], oss_k, b4.x);
+        o[4 * q + 1] = __builtin_fmaf(acc[1][4 * q + 1], oss_k, b4.y);
+        o[4 * q + 2] = __builtin_fmaf(acc[1][4 * q + 2], oss_k, b4.z);
+        o[4 * q + 3] = __builtin_fmaf(acc[1][4 * q + 3], oss_k, b4.w);
+      }
+      unsigned Hh[4][2], Lo[4][2];
+      split16(o, Hh, Lo);
+      quad_to_operand(Hh);
+      quad_to_operand(Lo);
+      typedef __attribute__((address_space(3))) u32x4* lds_u128_t;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        *(lds_u128_t)(unsigned long long)(k_wr + (unsigned)(((2 * c + half) ^ ksz) << 7)) =
+            u32x4{Hh[2 * c][0], Hh[2 * c][1], Hh[2 * c + 1][0], Hh[2 * c + 1][1]};
+        *(lds_u128_t)(unsigned long long)(k_wr + (unsigned)(((4 + 2 * c + half) ^ ksz) << 7)) =
+            u32x4{Lo[2 * c][0], Lo[2 * c][1], Lo[2 * c + 1][0], Lo[2 * c + 1][1]};
+      }
+    }
+    {  // v (normal form): lane = feature d = l31, register r = 4 q + e <-> key 8 q + 4 half + e of the wave's key block:
+       // a quad is one 8-byte unit 2 q + half of the block's feature row (hi), + 8 (lo), stored at unit ^ vt_swz(d)
+      const float bz = par[2 * D + head * 32 + l31];
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(acc[2][r], oss_v, bz);
+      unsigned Hh[4][2], Lo[4][2];
+      split16(o, Hh, Lo);
+      typedef __attribute__((address_space(3))) u32x2* lds_u64_t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *(lds_u64_t)(unsigned long long)(v_wr + (unsigned)(((2 * q + half) ^ vsz) << 3)) = u32x2{Hh[q][0], Hh[q][1]};
+        *(lds_u64_t)(unsigned long long)(v_wr + (unsigned)(((2 * q + half + 8) ^ vsz) << 3)) = u32x2{Lo[q][0], Lo[q][1]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = zero16;
+  };
+
+  // ================================================================ attention of one head in twelve slices of up to seven chunks
+  // (attention_img.hip's arithmetic, T = 4, the distance table in LDS, a single key tile per item: no online rescaling).  Chunk i of
+  // the stage's slice is issued in front of projection group i (chunk 6 behind the last group): the source order IS the schedule
+  // (sched_barrier between the pieces).
+  //   slice 0 / 1   S^T tiles (0, 1) / (2, 3): the two tiles' MFMA triples alternate (independent accumulators)
+  //   slice 2       M0 M1 W0 W1          band tiles 0, 1: R^T = E Q^T (accumulators racc[0], racc[1]) and their scratch writes
+  //   slice 3 4 5   M(s-1) G(s-3) W(s-1) the next band tile, the gather of pair s-3 into S^T tile T-1-(s-3), the tile's scratch write
+  //   slice 6       G3, key mask, row maximum
+  //   slice 7 / 8   exponentials of tiles (0, 1) / (2, 3), row sum
+  //   slice 9 / 10  O^T += V^T P^T over key tiles (0, 1) / (2, 3)
+  //   slice 11      ctx block: normalise, split, store
+  u32x4 kfa[4], kfb[4];  // K fragments of two S^T tiles / the table rows of two band tiles: [hi c0, hi c1, lo c0, lo c1]
+  float gth[16];         // gathered band values
+  float psum = 0.f;
+  f16x8 pvh, pvl, pph, ppl;  // V^T and P operands of the next P V triple
+  auto k_reads = [&](auto TT, u32x4 (&kf)[4]) __attribute__((always_inline)) {
+    constexpr int t = decltype(TT)::value;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      kf[c] = lds_u128(k_rd + (unsigned)(t * 4096 + (((2 * c + half) ^ ksz) << 7)));
+      kf[2 + c] = lds_u128(k_rd + (unsigned)(t * 4096 + (((4 + 2 * c + half) ^ ksz) << 7)));
+    }
+  };
+  auto s_mm = [&](auto TT, auto CC, const u32x4 (&kf)[4]) __attribute__((always_inline)) {  // S^T tile t, k16 step c: kh qh | kh ql | kl qh
+    constexpr int t = decltype(TT)::value, c = decltype(CC)::value;
+    const f16x8 kh = __builtin_bit_cast(f16x8, kf[c]), kl = __builtin_bit_cast(f16x8, kf[2 + c]);
+    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
+    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
+    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+  };
+  auto e_reads = [&](auto QQ, u32x4 (&e)[4]) __attribute__((always_inline)) {  // e[0] hi c0, e[1] hi c1, e[2] lo c0, e[3] lo c1 of the lane's band row
+    constexpr int qq = decltype(QQ)::value;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = lds_u128(eaddr[k] + (unsigned)(qq * 4096));
+  };
+  // R^T tile qq (rows = band rows pi(i), columns = this wave's queries) -> racc[qq & 1]: eh0 qh0 | el0 qh0 | eh0 ql0, then the same for k16 step 1
+  auto m_mm = [&](auto QQ, auto CC, const u32x4 (&e)[4]) __attribute__((always_inline)) {
+    constexpr int qq = decltype(QQ)::value, c = decltype(CC)::value;
+    const f16x8 eh = __builtin_bit_cast(f16x8, e[c]), el = __builtin_bit_cast(f16x8, e[2 + c]);
+    f32x16 ra = racc[qq & 1];
+    ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, qh[c], c == 0 ? zero16 : ra, 0, 0, 0);
+    ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(el, qh[c], ra, 0, 0, 0);
+    ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, ql[c], ra, 0, 0, 0);
+    racc[qq & 1] = ra;
+  };
+  auto op_W = [&](auto QQ) __attribute__((always_inline)) {  // scratch slot qq & 1 <- racc[qq & 1]: register r of all 64 lanes lands as band rows 2 r, 2 r + 1
+    constexpr int qq = decltype(QQ)::value;
+    const f32x16 ra = racc[qq & 1];
+    const unsigned m0v = rw_lds + (unsigned)((qq & 1) * 4096);
+    unsigned keep;
+    asm volatile(
+        "s_nop 7\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 2\n\t"
+        "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
+        "ds_write_addtid_b32 %3 offset:512\n\tds_write_addtid_b32 %4 offset:768\n\t"
+        "ds_write_addtid_b32 %5 offset:1024\n\tds_write_addtid_b32 %6 offset:1280\n\t"
+        "ds_write_addtid_b32 %7 offset:1536\n\tds_write_addtid_b32 %8 offset:1792\n\t"
+        "ds_write_addtid_b32 %9 offset:2048\n\tds_write_addtid_b32 %10 offset:2304\n\t"
+        "ds_write_addtid_b32 %11 offset:2560\n\tds_write_addtid_b32 %12 offset:2816\n\t"
+        "ds_write_addtid_b32 %13 offset:3072\n\tds_write_addtid_b32 %14 offset:3328\n\t"
+        "ds_write_addtid_b32 %15 offset:3584\n\tds_write_addtid_b32 %16 offset:3840\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]), "v"(ra[7]),
+          "v"(ra[8]), "v"(ra[9]), "v"(ra[10]), "v"(ra[11]), "v"(ra[12]), "v"(ra[13]), "v"(ra[14]), "v"(ra[15]),
+          "s"(m0v)
+        : "memory");
+  };
+  // S^T tile T-1-q += r_scale * band value of the tile pair (q, q+1): one ds_read_b32 (immediate offset) and one fma per score
+  auto g_reads = [&](auto Q) __attribute__((always_inline)) {
+    constexpr int q = decltype(Q)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int klr = (r & 3) + 8 * (r >> 2);
+      if constexpr ((q & 1) == 0) gth[r] = lds_f32(gb + (unsigned)((27 - klr) * 128));
+      else gth[r] = lds_f32(rw_base | ((gwrap + (unsigned)((27 - klr) * 128)) & 8191u));
+    }
+  };
+  auto g_fma = [&](auto Q) __attribute__((always_inline)) {
+    constexpr int t = T - 1 - decltype(Q)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[t][r] = __builtin_fmaf(gth[r], p.r_scale, sacc[t][r]);
+  };
+  // exponentials of elements [lo, hi) of the 32 scores of tiles (2 s7, 2 s7 + 1), summed in element order
+  auto exp_range = [&](int tbase, int lo, int hi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      if (e < lo || e >= hi) continue;
+      const int t = tbase + (e >> 4), r = e & 15;
+      const float pexp = exp2_neg(__builtin_fmaf(sacc[t][r], s_scale, nm));
+      sacc[t][r] = pexp;
+      psum += pexp;
+    }
+  };
+  // P V over key tile t, k16 step c: operands (split of eight probabilities, four 8-byte V^T units), then vh ph | vl ph | vh pl
+  auto pv_prep = [&](auto TT, auto CC) __attribute__((always_inline)) {
+    constexpr int t = decltype(TT)::value, c = decltype(CC)::value;
+    u32x4 phu, plu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned hv, lv;
+      split_pair(sacc[t][8 * c + 2 * j], sacc[t][8 * c + 2 * j + 1], hv, lv);
+      phu[j] = hv;
+      plu[j] = lv;
+    }
+    pph = __builtin_bit_cast(f16x8, phu);
+    ppl = __builtin_bit_cast(f16x8, plu);
+    typedef const __attribute__((address_space(3))) u32x2* lds_cu64_t;
+    const unsigned blk = v_rd + (unsigned)(t * 4096);
+    const int ua = 4 * c + half;
+    const u32x2 vh0 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)((ua ^ vsz) << 3));
+    const u32x2 vh1 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)(((ua + 2) ^ vsz) << 3));
+    const u32x2 vl0 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)(((ua + 8) ^ vsz) << 3));
+    const u32x2 vl1 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)(((ua + 10) ^ vsz) << 3));
+    pvh = __builtin_bit_cast(f16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
+    pvl = __builtin_bit_cast(f16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
+  };
+  auto pv_mm = [&](auto FIRST) __attribute__((always_inline)) {
+    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pvh, pph, decltype(FIRST)::value ? zero16 : oacc, 0, 0, 0);
+    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pvl, pph, oacc, 0, 0, 0);
+    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pvh, ppl, oacc, 0, 0, 0);
+  };
+  u32x4 ch0, ch1, cl0, cl1;  // the packed ctx block between slice 11's chunks
+  // `ahead`: the head this attention belongs to
+  auto attn_chunk = [&](auto S, auto I, int ahead) __attribute__((always_inline)) {
+    constexpr int s = decltype(S)::value, i = decltype(I)::value;
+    if (FDMI_SA_DBG & 1) return;
+    if constexpr (s == 0 || s == 1) {
+      constexpr int ta = 2 * s, tb = 2 * s + 1;
+      if constexpr (i == 0) k_reads(IC<ta>{}, kfa);
+      if constexpr (i == 1) { s_mm(IC<ta>{}, IC<0>{}, kfa); k_reads(IC<tb>{}, kfb); }
+      if constexpr (i == 2) s_mm(IC<tb>{}, IC<0>{}, kfb);
+      if constexpr (i == 3) s_mm(IC<ta>{}, IC<1>{}, kfa);
+      if constexpr (i == 4) s_mm(IC<tb>{}, IC<1>{}, kfb);
+    }
+    if constexpr (s == 2) {
+      if constexpr (i == 0) { e_reads(IC<0>{}, kfa); e_reads(IC<1>{}, kfb); }
+      if constexpr (i == 1) m_mm(IC<0>{}, IC<0>{}, kfa);
+      if constexpr (i == 2) m_mm(IC<1>{}, IC<0>{}, kfb);
+      if constexpr (i == 3) m_mm(IC<0>{}, IC<1>{}, kfa);
+      if constexpr (i == 4) m_mm(IC<1>{}, IC<1>{}, kfb);
+      if constexpr (i == 5) op_W(IC<0>{});
+      if constexpr (i == 6) op_W(IC<1>{});
+    }
+    if constexpr (s >= 3 && s <= 5) {
+      constexpr int m = s - 1, q = s - 3;
+      if constexpr (i == 0) { e_reads(IC<m>{}, kfa); g_reads(IC<q>{}); }
+      if constexpr (i == 1) m_mm(IC<m>{}, IC<0>{}, kfa);
+      if constexpr (i == 2) m_mm(IC<m>{}, IC<1>{}, kfa);
+      if constexpr (i == 3) g_fma(IC<q>{});
+      if constexpr (i == 5) op_W(IC<m>{});
+    }
+    if constexpr (s == 6) {
+      if constexpr (i == 0) g_reads(IC<3>{});
+      if constexpr (i == 1) g_fma(IC<3>{});
+      if constexpr (i == 2) {
+        // key mask (log2 domain comes later): this lane + its partner (lane ^ 32) hold one query's scores
+        if (len < LP) {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float sc = sacc[t][r];
+              if (key >= len) sc += mask_raw;  // (1 - mask) * -10000   (modelling.py:452)
+              if (key >= Lb) sc = -INFINITY;   // not a key at all (rows that do not exist)
+              sacc[t][r] = sc;
+            }
+        }
+      }
+      if constexpr (i == 3) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[t][r]);
+        mt = m;
+      }
+      if constexpr (i == 4) {
+        float m = mt;
+#pragma unroll
+        for (int t = 2; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[t][r]);
+        mt = m;
+      }
+      if constexpr (i == 5) {
+        mt = pair_max(mt);
+        nm = __builtin_fmaf(-mt, s_scale, 10.0f);  // + log2(PS): p' = PS * 2^((u - m) * s_scale)
+        static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
+        psum = 0.f;
+      }
+    }
+    if constexpr (s == 7 || s == 8) {
+      constexpr int st[8] = {0, 5, 10, 15, 20, 24, 28, 32};
+      exp_range(2 * (s - 7), st[i], st[i + 1]);
+      if constexpr (s == 8 && i == 6) l_run = pair_sum(psum);  // carries the factor PS
+    }
+    if constexpr (s == 9 || s == 10) {
+      constexpr int ta = 2 * (s - 9), tb = ta + 1;
+      if constexpr (i == 0) pv_prep(IC<ta>{}, IC<0>{});
+      if constexpr (i == 1) { pv_mm(IC<(ta == 0) ? 1 : 0>{}); pv_prep(IC<ta>{}, IC<1>{}); }
+      if constexpr (i == 2) { pv_mm(IC<0>{}); pv_prep(IC<tb>{}, IC<0>{}); }
+      if constexpr (i == 3) { pv_mm(IC<0>{}); pv_prep(IC<tb>{}, IC<1>{}); }
+      if constexpr (i == 4) pv_mm(IC<0>{});
+    }
+    if constexpr (s == 11) {
+      // ctx[token row][head block] = O^T[d][query] / l_run at the ctx image's scale (attention_img.hip: flush_ctx)
+      if constexpr (i == 1) {
+        const float onorm = p.ctx_scale / (p.v_scale * l_run);
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = oacc[r] * onorm;
+        pack_block(o, 1.0f, ch0, ch1, cl0, cl1);
+      }
+      if constexpr (i == 2) {
+        const int l = 32 * wq + l31;
+        const int row = row0 + l;
+        const unsigned voff = l < nrows ? (unsigned)((((row >> 5) * H * 8 + 2 * half) * 32 + (row & 31)) * 16) : 0xFFFFFF00u;
+        const int hoff = ahead * 4096;
+        const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0xFFFFFF00u, 0x00020000);
+        if (!(FDMI_SA_DBG & 4)) {
+          __builtin_amdgcn_raw_buffer_store_b128(ch0, rsc, (int)voff, hoff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ch1, rsc, (int)voff, hoff + 512, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(cl0, rsc, (int)voff, hoff + 4 * 512, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(cl1, rsc, (int)voff, hoff + 5 * 512, 0);
+          store_guard(ch0, ch1);
+          store_guard(cl0, cl1);
+        }
+      }
+    }
+  };
+  // the attention chunks in front of projection group `gap` (gap 6: behind the last group).  d_model 384: one slice per stage,
+  // chunk = gap.  d_model 192 (six stages, two slices A, B per stage, NOT interleaved with each other: they share registers):
+  // gaps 0-2 run A's chunks 0..5 two at a time, gap 3 A's chunk 6 and B's chunk 0, gaps 4-6 B's chunks 1..6 two at a time.
+  auto attn_gap = [&](auto KT, auto GAP, int ahead) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value, gap = decltype(GAP)::value;
+    if constexpr (SPS == 1) {
+      attn_chunk(IC<kt>{}, IC<gap>{}, ahead);
+    } else {
+      constexpr int a = 2 * kt, b = 2 * kt + 1;
+      if constexpr (gap < 3) { attn_chunk(IC<a>{}, IC<2 * gap>{}, ahead); attn_chunk(IC<a>{}, IC<2 * gap + 1>{}, ahead); }
+      if constexpr (gap == 3) { attn_chunk(IC<a>{}, IC<6>{}, ahead); attn_chunk(IC<b>{}, IC<0>{}, ahead); }
+      if constexpr (gap > 3) { attn_chunk(IC<b>{}, IC<2 * gap - 7>{}, ahead); attn_chunk(IC<b>{}, IC<2 * gap - 6>{}, ahead); }
+    }
+  };
+
+  // ================================================================ the item stream.  Item i = (sequence i / H of this workgroup,
+  // head i % H); iteration i runs the projection of item i fused with the attention of item i - 1 -- across sequences too: the
+  // hidden state of the next sequence replaces the current one IN PLACE, k-tile by k-tile, each right behind its last use in the
+  // sequence's last head (twelve stages before its first use).  Iteration 0's attention works on garbage (its stores are dropped:
+  // nrows = 0); the last iteration has no projection (wave-uniform branches around its stages' projection parts).
+  // One loop body = one register allocation: with separate code for the first / last head of a sequence hipcc moved ~200
+  // registers through scratch at every seam (44 k cycles each, profiles/r05_seq_attn_notes.log).
+  int seq = blockIdx.x;
+  if (seq >= p.B) {
+    FD_WAIT_VM(0);
+    return;
+  }
+  const int nitems = nseq * H;
+  int p_row0 = p.seq_row0[seq];  // first row of the sequence being projected
+  static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) { load_h_kt(KT, p_row0); });
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc[j] = zero16;
+  issue_w();
+  issue_w();
+  issue_w();
+  int head = 0;
+  for (int it = 0; it <= nitems; ++it) {
+    const bool do_proj = it < nitems;
+    // vector-memory bookkeeping of the stage-top waits: 0 plain (the 6 pieces of the two younger stages); 1 this iteration
+    // re-loads the hidden state (4 more loads per stage); 2 the iteration after such a one
+    const bool reload = do_proj && head == H - 1 && seq + (int)gridDim.x < p.B;
+    const int n_row0 = reload ? sload(p.seq_row0, seq + (int)gridDim.x) : 0;
+    const bool after_reload = do_proj && head == 0 && it > 0;
+    static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
+      constexpr int kt = decltype(KT)::value;
+      FD_STAMP(kt);
+      if (do_proj) {
+        // this stage landed: loads retire in order, so it is complete once no more loads are outstanding than were issued behind
+        // it (stores in flight only make the wait conservative).  Behind stage s: the 3 pieces of s+1 and of s+2, and -- while
+        // the hidden state is being re-loaded -- the 4 loads issued at the end of stages s-2 and s-1
+        if (reload) {
+          if constexpr (kt == 0) FD_WAIT_VM(6);
+          else if constexpr (kt == 1) FD_WAIT_VM(10);
+          else FD_WAIT_VM(14);
+        } else if (after_reload) {
+          if constexpr (kt == 0) FD_WAIT_VM(14);
+          else if constexpr (kt == 1) FD_WAIT_VM(10);
+          else FD_WAIT_VM(6);
+        } else {
+          FD_WAIT_VM(6);
+        }
+        barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
+        issue_w();
+        proj_top();
+      } else {
+        if constexpr (kt == 0) barrier_keep_vm();  // K / V of the last head are complete
+      }
+      FD_SB();
+      static_for<0, 6>([&](auto G) __attribute__((always_inline)) {
+        attn_gap(KT, G, head == 0 ? H - 1 : head - 1);
+        FD_SB();
+        if (do_proj) proj_group(KT, G);
+        FD_SB();
+      });
+      attn_gap(KT, IC<6>{}, head == 0 ? H - 1 : head - 1);
+      FD_SB();
+      if (reload) load_h_kt(KT, n_row0);
+      FD_SB();
+      if (do_proj) ++pos;
+    });
+    if (do_proj) epilogue(head);
+    ++slot;
+    // the attention that starts now belongs to the sequence just projected
+    if (do_proj && head == 0) {
+      row0 = p_row0;
+      nrows = sload(p.seq_row0, seq + 1) - row0;
+      Lb = sload(p.nrow, seq);
+      len = sload(p.lens, seq);
+    }
+    if (++head == H) {
+      head = 0;
+      seq += (int)gridDim.x;
+      p_row0 = n_row0;
+    }
+  }
+  FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
+#undef FD_STAMP
+#undef FD_SB
+}
+
+static int n_cu_of(int dev) {
+  static int cached[64] = {0};
+  if (dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    hipDeviceProp_t prop;
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cached[dev];
+}
+
+template <int NKT>
+static void launch(const SeqAttnArgs& p, hipStream_t s) {
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attn_kernel<NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attn_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set[dev] = true;
+  }
+  int grid = n_cu_of(dev);
+  if (grid > p.B) grid = p.B;
+  if (p.stamps) hipLaunchKernelGGL((seq_attn_kernel<NKT, true>), dim3(grid), dim3(256), SMEM, s, p);
+  else hipLaunchKernelGGL((seq_attn_kernel<NKT, false>), dim3(grid), dim3(256), SMEM, s, p);
+}
+
+}  // namespace sa
+
+// head size 32, d_model 384 / 192 (every released configuration / the reference's test fixture), a sequence = one tile of 128 keys
+// with all four 32-key tiles in use, the distance table in 32 KiB of LDS
+bool seq_attn_supported(int d_model, int n_heads, int L, int maxpos) {
+  return (d_model == 384 || d_model == 192) && n_heads * 32 == d_model && L > 96 && L <= 128 && maxpos <= 128 && maxpos >= L;
+}
+
+void launch_seq_attn(const SeqAttnArgs& p, hipStream_t s) {
+  if (p.H == 12) sa::launch<12>(p, s);
+  else sa::launch<6>(p, s);
+}
+
+}  // namespace fdmi

@@ -12,8 +12,8 @@ OUT=foldingdiff_amd/_lib/$V; mkdir -p $OUT/obj
 # api.hip includes ../../include/fdmi.h relative to csrc
 mkdir -p $TMP/x/y && mv $TMP/csrc $TMP/x/y/csrc && mv $TMP/include $TMP/x/include
 pids=()
-for f in api gemm_f32 gemm_img gemm_ws gemm_ln_rows attention_f32 attention_img attention_gen rowwise rowwise_img nerf; do
-  extra=""; { [ "$f" = attention_img ] || [ "$f" = attention_gen ]; } && extra="-fno-slp-vectorize"
+for f in api gemm_f32 gemm_img gemm_ws gemm_ln_rows attention_f32 attention_img attention_gen seq_attn rowwise rowwise_img nerf; do
+  extra=""; { [ "$f" = attention_img ] || [ "$f" = attention_gen ] || [ "$f" = seq_attn ]; } && extra="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra "$@" -c $TMP/x/y/csrc/$f.hip -o $OUT/obj/$f.o &
   pids+=($!)
 done
