@@ -103,7 +103,7 @@ struct Workspace {
   }
 };
 
-constexpr long long kStampWords = 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16;
+constexpr long long kStampWords = 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16 + 16384;  // (+ 32 K floats of register dumps, seq_attn.hip FDMI_SA_DUMP)
 
 struct PendingEvent {
   int cls;

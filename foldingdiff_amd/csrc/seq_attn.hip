@@ -152,23 +152,25 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   const unsigned gwrap = (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31) + 4096u;  // offset inside the scratch, before wrapping
   const unsigned rw_base = lds_addr(Rw);
   static_assert(OFF_R % 8192 == 0, "the skew scratch of a wave must be 8 KiB aligned");
-  unsigned eaddr[4];
+  // band tile operand rows (attention_img.hip, ELDS): MFMA row l31 -> band row pi31 of the tile; unit u of LDS row rp sits at position
+  // u ^ ((rp >> 1) & 7).  The lane's four units 2 k + half, k = 0..3, differ from unit `half` in bits 1-2 only, and the XOR commutes:
+  // address of unit 2 k + half = eaddr0 ^ (32 k) -- one register instead of four
+  unsigned eaddr0;
   {
-    const int rho0 = p.maxpos - LP + esh + 32 * wq;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rp = rho0 + pi31;
-      eaddr[k] = lds_addr(Es) + (unsigned)(rp * 128 + (((2 * k + half) ^ ((rp >> 1) & 7)) << 4));
-      asm volatile("" : "+v"(eaddr[k]));
-    }
+    const int rp = p.maxpos - LP + esh + 32 * wq + pi31;
+    eaddr0 = lds_addr(Es) + (unsigned)(rp * 128 + ((half ^ ((rp >> 1) & 7)) << 4));
+    asm volatile("" : "+v"(eaddr0));
   }
   // K / V addresses of this lane: key (row) 32 wq + l31 of the head's K tile, feature row l31 of the V^T blocks
   const int ksz = (l31 >> 3) & 1;
-  const unsigned k_rd = lds_addr(Ks) + (unsigned)((l31 >> 3) * 1024 + (l31 & 7) * 16);  // + 4096 t + ((unit ^ ksz) << 7)
+  // the lane's units 2 c + 4 plane + half sit at positions (2 c + 4 plane + half) ^ ksz = 2 c + 4 plane + (half ^ ksz): the lane part
+  // is folded into the base, the rest is an immediate offset
+  const unsigned k_rd = lds_addr(Ks) + (unsigned)((l31 >> 3) * 1024 + (l31 & 7) * 16 + ((half ^ ksz) << 7));  // + 4096 t + (2 c + 4 plane) * 128
   const unsigned k_wr = k_rd + (unsigned)(wq * 4096);
   const int vsz = vt_swz(l31);
   const unsigned v_rd = lds_addr(Vt) + (unsigned)(l31 * 128);  // + 4096 t + ((unit ^ vsz) << 3)
   const unsigned v_wr = v_rd + (unsigned)(wq * 4096);
+  const unsigned par_base = __builtin_amdgcn_readfirstlane(lds_addr(par));
   const unsigned w_rd = lds_addr(Wr) + (unsigned)(l31 * 16 + half * 1536);  // + slot * KT_BYTES + (2 c + 4 plane) * 1536 + 512 j
 
   const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   // ---- the weight stream: positions (sequence, head, k-tile) of this workgroup, one 12 KiB stage each; the stream does not stop at
   // a sequence's end (the next sequence's first stages are requested during the last head)
   const int nseq = (p.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = nseq * H * NKT;
+  const int total = (nseq * H + 1) * NKT;  // (the last iteration projects the last head once more: see the item stream)
   int pos = 0;   // position being computed
   int wsrc = 0;  // (head, k-tile) index of the next position to request, 0 .. H NKT - 1
   int wreq = 0;  // positions requested so far
@@ -207,8 +209,10 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   // the lane's rows of k-tile kt of the hidden state of the sequence whose first row is r0 (rows beyond the image read as zeros)
   auto load_h_kt = [&](auto KT, int r0) __attribute__((always_inline)) {
     constexpr int kt = decltype(KT)::value;
-    const int row = r0 + 32 * wq + l31;
-    const unsigned hoff = (unsigned)(((row >> 5) * (NKT * 256) + (row & 31)) * 16 + half * 512);
+    int ln;  // (an opaque copy of the lane index: nothing derived from it lives across the loop, see ctx_store)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int row = r0 + 32 * wq + (ln & 31);
+    const unsigned hoff = (unsigned)(((row >> 5) * (NKT * 256) + (row & 31)) * 16 + (ln >> 5) * 512);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       hh[kt][c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, (int)hoff, (kt * 8 + 2 * c) * 512, 0));
@@ -221,45 +225,76 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 64 && lane == 0) st[slot * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define FD_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef FDMI_SA_DUMP
+#define FDMI_SA_DUMP 0  // debug build: wave 0 of workgroup 0 dumps registers of the attention that runs in iteration FDMI_SA_DUMP (needs FDMI_STAMPS=1)
+#endif
+  // register dump: out[(base + i) * 64 + lane] = value i of this lane
+  auto dump16 = [&](int base, const f32x16& v) __attribute__((always_inline)) {
+    if constexpr (FDMI_SA_DUMP != 0 && PROF) {
+      if (blockIdx.x == 0 && wq == 0 && slot == FDMI_SA_DUMP && p.stamps != nullptr) {
+        float* out = reinterpret_cast<float*>(p.stamps + 4 * 64 * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(base + r) * 64 + lane] = v[r];
+      }
+    }
+  };
 
   // ================================================================ projection: one stage = one k-tile of the head's 96 weight rows =
-  // six groups of three MFMAs (one per accumulator: consecutive MFMAs never share one; per accumulator the order of gemm_img.hip,
-  // wh ah | wh al | wl ah per k16 step).  Two fragment buffers: X = the hi plane of the step, Y = its lo plane; the next step's planes
-  // are requested right behind the last group that reads the buffer, i.e. at least one group (96 matrix cycles) + one attention chunk
-  // before their first use.
+  // eighteen MFMAs in six groups of three (one per accumulator: consecutive MFMAs never share one; per accumulator the order of
+  // gemm_img.hip, wh ah | wh al | wl ah per k16 step).  Two fragment buffers: X = the hi plane of the step, Y = its lo plane; the next
+  // step's planes are requested right behind the last MFMA that reads the buffer, at least three MFMAs before their first use.
   f16x8 Xw[3], Yw[3];
   unsigned wb = 0;  // this lane's fragment base inside the stage being computed
   auto rd_w = [&](f16x8 (&dst)[3], int unit) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) dst[j] = __builtin_bit_cast(f16x8, lds_u128(wb + (unsigned)(unit * 1536 + j * 512)));
   };
-  auto mm3 = [&](const f16x8 (&w)[3], const f16x8& hf) __attribute__((always_inline)) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], hf, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], hf, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf, w[2], acc[2], 0, 0, 0);  // v: normal form (lane = feature)
-  };
   auto proj_top = [&]() __attribute__((always_inline)) {
     wb = w_rd + (unsigned)((pos & (NST - 1)) * KT_BYTES);
     rd_w(Xw, 0);
     rd_w(Yw, 4);
   };
-  auto proj_group = [&](auto KT, auto G) __attribute__((always_inline)) {
-    constexpr int kt = decltype(KT)::value, g = decltype(G)::value;
+  // MFMA k = 3 g + j of the stage: group g, accumulator j (q | k in the swapped form, v in the normal form: lane = feature)
+  auto proj_mfma = [&](auto KT, auto K) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value, k = decltype(K)::value, g = k / 3, j = k % 3;
     if (FDMI_SA_DBG & 2) return;
-    if constexpr (g == 0) mm3(Xw, hh[kt][0]);
-    if constexpr (g == 1) { mm3(Xw, hl[kt][0]); rd_w(Xw, 2); }
-    if constexpr (g == 2) { mm3(Yw, hh[kt][0]); rd_w(Yw, 6); }
-    if constexpr (g == 3) mm3(Xw, hh[kt][1]);
-    if constexpr (g == 4) mm3(Xw, hl[kt][1]);
-    if constexpr (g == 5) mm3(Yw, hh[kt][1]);
+    const f16x8& w = (g == 2 || g == 5) ? Yw[j] : Xw[j];
+    const f16x8& hf = (g == 1 || g == 4) ? hl[kt][g / 3] : hh[kt][g / 3];
+    if constexpr (j < 2) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, hf, acc[j], 0, 0, 0);
+    else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf, w, acc[2], 0, 0, 0);
+    if constexpr (k == 5) rd_w(Xw, 2);  // X is free: the hi plane of k16 step 1
+    if constexpr (k == 8) rd_w(Yw, 6);  // Y is free: the lo plane of k16 step 1
   };
 
-  // ---- the head's epilogue: q_h -> operand registers, k_h -> LDS (unit-major pieces), v_h -> LDS (V^T blocks); accumulators zeroed
-  auto split16 = [&](const float (&o)[16], unsigned (&Hh)[4][2], unsigned (&Lo)[4][2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int dd = 0; dd < 2; ++dd) split_pair(o[4 * q + 2 * dd], o[4 * q + 2 * dd + 1], Hh[q][dd], Lo[q][dd]);
+  // ================================================================ the attention of one head, software pipelined into the 18 MFMA
+  // slots of each of the twelve stages of the NEXT head's projection: slot k of the stage's slice is issued right behind projection
+  // MFMA k, so an attention MFMA always has a projection MFMA between itself and the next one of its accumulator chain (a dependent
+  // MFMA issues 64 cycles after its predecessor, an independent one after 32: with chunks of three dependent MFMAs between the
+  // projection groups the fused stage took LONGER than the two kernels' stages together, profiles/r05_seq_attn_notes.log), and the
+  // VALU / LDS work of a slot runs in the shadow of that MFMA.  The source order IS the schedule (sched_barrier between the pieces).
+  //   stage 0       ctx block of the head before (normalise, split, store); then the head's projection epilogue: the three 32 x 32
+  //                 accumulators (copied out at the stage's top) -> q_h operand registers, k_h -> LDS, v_h -> LDS
+  //   stage 1 / 2   S^T tiles (0, 1) / (2, 3): the two tiles' MFMAs alternate
+  //   stage 3       M0 M1 W0 W1          band tiles 0, 1: R^T = E Q^T (accumulators racc[0], racc[1]) and their scratch writes
+  //   stage 4 5 6   M(s-2) G(s-4) W(s-2) the next band tile, the gather of pair s-4 into S^T tile T-1-(s-4), the tile's scratch write
+  //   stage 7       G3, key mask, row maximum
+  //   stage 8 / 9   exponentials of tiles (0, 1) / (2, 3), row sum
+  //   stage 10 / 11 O^T += V^T P^T over key tiles (0, 1) / (2, 3)
+  // (d_model 192: six stages, two slices each: the first slice in slots 0-8, two of its slots at a time, the second in slots 9-17.)
+  f32x16 eo[3];          // the projected head's accumulators, copied out at the top of stage 0
+  u32x4 kfa[4], kfb[4];  // K fragments of two S^T tiles / the table rows of two band tiles: [hi c0, hi c1, lo c0, lo c1]
+  float gth[16];         // gathered band values
+  float psum = 0.f;
+  f16x8 pvh, pvl, pph, ppl;  // V^T and P operands of the next P V triple
+  u32x4 ch0, ch1, cl0, cl1;  // the packed ctx block
+  float co[16];              // ... and its values
+  unsigned eHh[4][2], eLo[4][2];  // split halves of the epilogue block being assembled
+  int a_head = 0;  // head of the attention in flight (the ctx block of stage 0 belongs to it)
+
+  auto split_quad = [&](auto Q, const float (&o)[4]) __attribute__((always_inline)) {
+    constexpr int q = decltype(Q)::value;
+    split_pair(o[0], o[1], eHh[q][0], eLo[q][0]);
+    split_pair(o[2], o[3], eHh[q][1], eLo[q][1]);
   };
   // quad layout (lane half h owns d = 8 q + 4 h + e) -> MFMA operand layout (lane half h owns units 2 c + h: d = 16 c + 8 h + 0..7):
   // the half-waves exchange quad 1 of the lower against quad 0 of the upper lanes, and quad 3 against quad 2
@@ -270,113 +305,120 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       swap32(X[2][dd], X[3][dd]);
     }
   };
-  auto epilogue = [&](int head) __attribute__((always_inline)) {
-    {  // q
-      float o[16];
+  // epilogue of the projected head `ph`, piece by piece (same arithmetic as gemm_img.hip's q | k and v^T epilogues):
+  auto epi_qk_quad = [&](auto J, auto Q, int ph) __attribute__((always_inline)) {  // J: 0 q, 1 k; quad Q of the lane's 16 features
+    constexpr int j = decltype(J)::value, q = decltype(Q)::value;
+    // (read through an integer LDS address: behind a pointer derived from `smem` hipcc assumes that the read may alias the LDS-DMA
+    // writes in flight and waits for the whole weight stream to land)
+    int ln;  // (an opaque copy of the lane index: see ctx_store)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const u32x4 braw = lds_u128(par_base + (unsigned)((j * D + ph * 32 + 8 * q) * 4) + (unsigned)((ln >> 5) * 16));
+    const float oss = j == 0 ? oss_q : oss_k;
+    float o[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(par + head * 32 + 8 * q + 4 * half);
-        o[4 * q + 0] = __builtin_fmaf(acc[0][4 * q + 0], oss_q, b4.x);
-        o[4 * q + 1] = __builtin_fmaf(acc[0][4 * q + 1], oss_q, b4.y);
-        o[4 * q + 2] = __builtin_fmaf(acc[0][4 * q + 2], oss_q, b4.z);
-        o[4 * q + 3] = __builtin_fmaf(acc[0][4 * q + 3], oss_q, b4.w);
-      }
-      unsigned Hh[4][2], Lo[4][2];
-      split16(o, Hh, Lo);
-      quad_to_operand(Hh);
-      quad_to_operand(Lo);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        qh[c] = __builtin_bit_cast(f16x8, u32x4{Hh[2 * c][0], Hh[2 * c][1], Hh[2 * c + 1][0], Hh[2 * c + 1][1]});
-        ql[c] = __builtin_bit_cast(f16x8, u32x4{Lo[2 * c][0], Lo[2 * c][1], Lo[2 * c + 1][0], Lo[2 * c + 1][1]});
-      }
-    }
-    {  // k: this lane's key is row 32 wq + l31 of the K tile; unit u at position u ^ (piece & 1)
-      float o[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(par + D + head * 32 + 8 * q + 4 * half);
-        o[4 * q + 0] = __builtin_fmaf(acc[1][4 * q + 0], oss_k, b4.x);
-        o[4 * q + 1] = __builtin_fmaf(acc[1][4 * q + 1], oss_k, b4.y);
-        o[4 * q + 2] = __builtin_fmaf(acc[1][4 * q + 2], oss_k, b4.z);
-        o[4 * q + 3] = __builtin_fmaf(acc[1][4 * q + 3], oss_k, b4.w);
-      }
-      unsigned Hh[4][2], Lo[4][2];
-      split16(o, Hh, Lo);
-      quad_to_operand(Hh);
-      quad_to_operand(Lo);
-      typedef __attribute__((address_space(3))) u32x4* lds_u128_t;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        *(lds_u128_t)(unsigned long long)(k_wr + (unsigned)(((2 * c + half) ^ ksz) << 7)) =
-            u32x4{Hh[2 * c][0], Hh[2 * c][1], Hh[2 * c + 1][0], Hh[2 * c + 1][1]};
-        *(lds_u128_t)(unsigned long long)(k_wr + (unsigned)(((4 + 2 * c + half) ^ ksz) << 7)) =
-            u32x4{Lo[2 * c][0], Lo[2 * c][1], Lo[2 * c + 1][0], Lo[2 * c + 1][1]};
-      }
-    }
-    {  // v (normal form): lane = feature d = l31, register r = 4 q + e <-> key 8 q + 4 half + e of the wave's key block:
-       // a quad is one 8-byte unit 2 q + half of the block's feature row (hi), + 8 (lo), stored at unit ^ vt_swz(d)
-      const float bz = par[2 * D + head * 32 + l31];
-      float o[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(acc[2][r], oss_v, bz);
-      unsigned Hh[4][2], Lo[4][2];
-      split16(o, Hh, Lo);
-      typedef __attribute__((address_space(3))) u32x2* lds_u64_t;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *(lds_u64_t)(unsigned long long)(v_wr + (unsigned)(((2 * q + half) ^ vsz) << 3)) = u32x2{Hh[q][0], Hh[q][1]};
-        *(lds_u64_t)(unsigned long long)(v_wr + (unsigned)(((2 * q + half + 8) ^ vsz) << 3)) = u32x2{Lo[q][0], Lo[q][1]};
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[j] = zero16;
+    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(eo[j][4 * q + e], oss, __builtin_bit_cast(float, (unsigned)braw[e]));
+    split_quad(Q, o);
   };
-
-  // ================================================================ attention of one head in twelve slices of up to seven chunks
-  // (attention_img.hip's arithmetic, T = 4, the distance table in LDS, a single key tile per item: no online rescaling).  Chunk i of
-  // the stage's slice is issued in front of projection group i (chunk 6 behind the last group): the source order IS the schedule
-  // (sched_barrier between the pieces).
-  //   slice 0 / 1   S^T tiles (0, 1) / (2, 3): the two tiles' MFMA triples alternate (independent accumulators)
-  //   slice 2       M0 M1 W0 W1          band tiles 0, 1: R^T = E Q^T (accumulators racc[0], racc[1]) and their scratch writes
-  //   slice 3 4 5   M(s-1) G(s-3) W(s-1) the next band tile, the gather of pair s-3 into S^T tile T-1-(s-3), the tile's scratch write
-  //   slice 6       G3, key mask, row maximum
-  //   slice 7 / 8   exponentials of tiles (0, 1) / (2, 3), row sum
-  //   slice 9 / 10  O^T += V^T P^T over key tiles (0, 1) / (2, 3)
-  //   slice 11      ctx block: normalise, split, store
-  u32x4 kfa[4], kfb[4];  // K fragments of two S^T tiles / the table rows of two band tiles: [hi c0, hi c1, lo c0, lo c1]
-  float gth[16];         // gathered band values
-  float psum = 0.f;
-  f16x8 pvh, pvl, pph, ppl;  // V^T and P operands of the next P V triple
-  auto k_reads = [&](auto TT, u32x4 (&kf)[4]) __attribute__((always_inline)) {
-    constexpr int t = decltype(TT)::value;
+  auto epi_q_finish = [&]() __attribute__((always_inline)) {
+    quad_to_operand(eHh);
+    quad_to_operand(eLo);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      kf[c] = lds_u128(k_rd + (unsigned)(t * 4096 + (((2 * c + half) ^ ksz) << 7)));
-      kf[2 + c] = lds_u128(k_rd + (unsigned)(t * 4096 + (((4 + 2 * c + half) ^ ksz) << 7)));
+      qh[c] = __builtin_bit_cast(f16x8, u32x4{eHh[2 * c][0], eHh[2 * c][1], eHh[2 * c + 1][0], eHh[2 * c + 1][1]});
+      ql[c] = __builtin_bit_cast(f16x8, u32x4{eLo[2 * c][0], eLo[2 * c][1], eLo[2 * c + 1][0], eLo[2 * c + 1][1]});
     }
   };
-  auto s_mm = [&](auto TT, auto CC, const u32x4 (&kf)[4]) __attribute__((always_inline)) {  // S^T tile t, k16 step c: kh qh | kh ql | kl qh
+  auto epi_k_finish = [&]() __attribute__((always_inline)) {  // this lane's key is row 32 wq + l31 of the K tile; unit u at position u ^ (piece & 1)
+    quad_to_operand(eHh);
+    quad_to_operand(eLo);
+    typedef __attribute__((address_space(3))) u32x4* lds_u128_t;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      *(lds_u128_t)(unsigned long long)(k_wr + (unsigned)(2 * c * 128)) =
+          u32x4{eHh[2 * c][0], eHh[2 * c][1], eHh[2 * c + 1][0], eHh[2 * c + 1][1]};
+      *(lds_u128_t)(unsigned long long)(k_wr + (unsigned)((4 + 2 * c) * 128)) =
+          u32x4{eLo[2 * c][0], eLo[2 * c][1], eLo[2 * c + 1][0], eLo[2 * c + 1][1]};
+    }
+  };
+  // v (normal form): lane = feature d = l31, register r = 4 q + e <-> key 8 q + 4 half + e of the wave's key block: a quad is one
+  // 8-byte unit 2 q + half of the block's feature row (hi), + 8 (lo), stored at unit ^ vt_swz(d)
+  auto epi_v_quad = [&](auto Q, int ph) __attribute__((always_inline)) {
+    constexpr int q = decltype(Q)::value;
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const float bz = lds_f32(par_base + (unsigned)((2 * D + ph * 32) * 4) + (unsigned)((ln & 31) * 4));
+    const float o[4] = {__builtin_fmaf(eo[2][4 * q + 0], oss_v, bz), __builtin_fmaf(eo[2][4 * q + 1], oss_v, bz),
+                        __builtin_fmaf(eo[2][4 * q + 2], oss_v, bz), __builtin_fmaf(eo[2][4 * q + 3], oss_v, bz)};
+    split_quad(Q, o);
+    typedef __attribute__((address_space(3))) u32x2* lds_u64_t;
+    *(lds_u64_t)(unsigned long long)(v_wr + (unsigned)(((2 * q + half) ^ vsz) << 3)) = u32x2{eHh[q][0], eHh[q][1]};
+    *(lds_u64_t)(unsigned long long)(v_wr + (unsigned)(((2 * q + half + 8) ^ vsz) << 3)) = u32x2{eLo[q][0], eLo[q][1]};
+  };
+  // ctx[token row][head block] = O^T[d][query] / l_run at the ctx image's scale (attention_img.hip: flush_ctx)
+  auto ctx_scale_block = [&]() __attribute__((always_inline)) {
+    const float onorm = p.ctx_scale / (p.v_scale * l_run);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) co[r] = oacc[r] * onorm;
+    if constexpr (FDMI_SA_DUMP != 0 && PROF) {  // (the ctx block of the dumped attention leaves one iteration later)
+      if (blockIdx.x == 0 && wq == 0 && slot == FDMI_SA_DUMP + 1 && p.stamps != nullptr) {
+        float* out = reinterpret_cast<float*>(p.stamps + 4 * 64 * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(240 + r) * 64 + lane] = oacc[r];
+        out[256 * 64 + lane] = l_run;
+      }
+    }
+  };
+  auto ctx_store = [&]() __attribute__((always_inline)) {
+    // (the lane indices are re-derived from an opaque copy: as values that live across the whole loop one of their derivatives was
+    // spilled, and its scratch reload -- a vector-memory load -- drained the weight stream once per iteration)
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int l = 32 * wq + (ln & 31);
+    const int row = row0 + l;
+    unsigned voff = (unsigned)((((row >> 5) * H * 8 + 2 * (ln >> 5)) * 32 + (row & 31)) * 16);
+    voff = l < nrows ? voff : 0xFFFFFF00u;
+    const int hoff = a_head * 4096;
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0xFFFFFF00u, 0x00020000);
+    if (!(FDMI_SA_DBG & 4)) {
+      __builtin_amdgcn_raw_buffer_store_b128(ch0, rsc, (int)voff, hoff, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ch1, rsc, (int)voff, hoff + 512, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(cl0, rsc, (int)voff, hoff + 4 * 512, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(cl1, rsc, (int)voff, hoff + 5 * 512, 0);
+      store_guard(ch0, ch1);
+      store_guard(cl0, cl1);
+    }
+  };
+
+  auto k_reads = [&](auto TT, auto CC, u32x4 (&kf)[4]) __attribute__((always_inline)) {  // K fragments (hi, lo) of tile t, k16 step c
     constexpr int t = decltype(TT)::value, c = decltype(CC)::value;
-    const f16x8 kh = __builtin_bit_cast(f16x8, kf[c]), kl = __builtin_bit_cast(f16x8, kf[2 + c]);
-    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], c == 0 ? zero16 : sacc[t], 0, 0, 0);
-    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc[t], 0, 0, 0);
-    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc[t], 0, 0, 0);
+    kf[c] = lds_u128(k_rd + (unsigned)(t * 4096 + 2 * c * 128));
+    kf[2 + c] = lds_u128(k_rd + (unsigned)(t * 4096 + (4 + 2 * c) * 128));
+  };
+  // MFMA i (0..5) of S^T tile t: k16 step i / 3, then kh qh | kh ql | kl qh
+  auto s_mm1 = [&](auto TT, auto I, const u32x4 (&kf)[4]) __attribute__((always_inline)) {
+    constexpr int t = decltype(TT)::value, i = decltype(I)::value, c = i / 3, j = i % 3;
+    const f16x8 a = __builtin_bit_cast(f16x8, kf[j == 2 ? 2 + c : c]);
+    const f16x8& b = j == 1 ? ql[c] : qh[c];
+    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, i == 0 ? zero16 : sacc[t], 0, 0, 0);
   };
   auto e_reads = [&](auto QQ, u32x4 (&e)[4]) __attribute__((always_inline)) {  // e[0] hi c0, e[1] hi c1, e[2] lo c0, e[3] lo c1 of the lane's band row
     constexpr int qq = decltype(QQ)::value;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = lds_u128(eaddr[k] + (unsigned)(qq * 4096));
+    for (int k = 0; k < 4; ++k) {
+#ifdef FDMI_SA_OLD_E
+      const int rp = p.maxpos - LP + esh + 32 * wq + pi31;
+      e[k] = lds_u128(lds_addr(Es) + (unsigned)(rp * 128 + (((2 * k + half) ^ ((rp >> 1) & 7)) << 4)) + (unsigned)(qq * 4096));
+#else
+      e[k] = lds_u128((eaddr0 ^ (unsigned)(32 * k)) + (unsigned)(qq * 4096));
+#endif
+    }
   };
-  // R^T tile qq (rows = band rows pi(i), columns = this wave's queries) -> racc[qq & 1]: eh0 qh0 | el0 qh0 | eh0 ql0, then the same for k16 step 1
-  auto m_mm = [&](auto QQ, auto CC, const u32x4 (&e)[4]) __attribute__((always_inline)) {
-    constexpr int qq = decltype(QQ)::value, c = decltype(CC)::value;
-    const f16x8 eh = __builtin_bit_cast(f16x8, e[c]), el = __builtin_bit_cast(f16x8, e[2 + c]);
-    f32x16 ra = racc[qq & 1];
-    ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, qh[c], c == 0 ? zero16 : ra, 0, 0, 0);
-    ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(el, qh[c], ra, 0, 0, 0);
-    ra = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, ql[c], ra, 0, 0, 0);
-    racc[qq & 1] = ra;
+  // MFMA i (0..5) of R^T tile qq (rows = band rows pi(i), columns = this wave's queries) -> racc[qq & 1]: eh qh | el qh | eh ql per k16 step
+  auto m_mm1 = [&](auto QQ, auto I, const u32x4 (&e)[4]) __attribute__((always_inline)) {
+    constexpr int qq = decltype(QQ)::value, i = decltype(I)::value, c = i / 3, j = i % 3;
+    const f16x8 a = __builtin_bit_cast(f16x8, e[j == 1 ? 2 + c : c]);
+    const f16x8& b = j == 2 ? ql[c] : qh[c];
+    racc[qq & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, i == 0 ? zero16 : racc[qq & 1], 0, 0, 0);
   };
   auto op_W = [&](auto QQ) __attribute__((always_inline)) {  // scratch slot qq & 1 <- racc[qq & 1]: register r of all 64 lanes lands as band rows 2 r, 2 r + 1
     constexpr int qq = decltype(QQ)::value;
@@ -400,7 +442,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
           "s"(m0v)
         : "memory");
   };
-  // S^T tile T-1-q += r_scale * band value of the tile pair (q, q+1): one ds_read_b32 (immediate offset) and one fma per score
+  // S^T tile T-1-q += r_scale * band value of the tile pair (q, q+1): one ds_read_b32 and one fma per score
   auto g_reads = [&](auto Q) __attribute__((always_inline)) {
     constexpr int q = decltype(Q)::value;
 #pragma unroll
@@ -410,12 +452,12 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       else gth[r] = lds_f32(rw_base | ((gwrap + (unsigned)((27 - klr) * 128)) & 8191u));
     }
   };
-  auto g_fma = [&](auto Q) __attribute__((always_inline)) {
-    constexpr int t = T - 1 - decltype(Q)::value;
+  auto g_fma4 = [&](auto Q, auto R0) __attribute__((always_inline)) {
+    constexpr int t = T - 1 - decltype(Q)::value, r0 = decltype(R0)::value;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[t][r] = __builtin_fmaf(gth[r], p.r_scale, sacc[t][r]);
+    for (int r = r0; r < r0 + 4; ++r) sacc[t][r] = __builtin_fmaf(gth[r], p.r_scale, sacc[t][r]);
   };
-  // exponentials of elements [lo, hi) of the 32 scores of tiles (2 s7, 2 s7 + 1), summed in element order
+  // exponentials of elements [lo, hi) of the 32 scores of tiles (tbase, tbase + 1), summed in element order
   auto exp_range = [&](int tbase, int lo, int hi) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
@@ -449,46 +491,67 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     pvh = __builtin_bit_cast(f16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
     pvl = __builtin_bit_cast(f16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
   };
-  auto pv_mm = [&](auto FIRST) __attribute__((always_inline)) {
-    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pvh, pph, decltype(FIRST)::value ? zero16 : oacc, 0, 0, 0);
-    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pvl, pph, oacc, 0, 0, 0);
-    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pvh, ppl, oacc, 0, 0, 0);
+  auto pv_mm1 = [&](auto J, auto FIRST) __attribute__((always_inline)) {  // J: 0 vh ph | 1 vl ph | 2 vh pl
+    constexpr int j = decltype(J)::value;
+    const f16x8& a = j == 1 ? pvl : pvh;
+    const f16x8& b = j == 2 ? ppl : pph;
+    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, (j == 0 && decltype(FIRST)::value) ? zero16 : oacc, 0, 0, 0);
   };
-  u32x4 ch0, ch1, cl0, cl1;  // the packed ctx block between slice 11's chunks
-  // `ahead`: the head this attention belongs to
-  auto attn_chunk = [&](auto S, auto I, int ahead) __attribute__((always_inline)) {
-    constexpr int s = decltype(S)::value, i = decltype(I)::value;
+
+  // slot k (0..17; -1: in front of the stage's first projection MFMA) of attention slice s.  `ph`: the head whose projection
+  // finished in the previous iteration (its epilogue is slice 0)
+  auto attn_slot = [&](auto S, auto K, int ph) __attribute__((always_inline)) {
+    constexpr int s = decltype(S)::value, k = decltype(K)::value;
     if (FDMI_SA_DBG & 1) return;
-    if constexpr (s == 0 || s == 1) {
-      constexpr int ta = 2 * s, tb = 2 * s + 1;
-      if constexpr (i == 0) k_reads(IC<ta>{}, kfa);
-      if constexpr (i == 1) { s_mm(IC<ta>{}, IC<0>{}, kfa); k_reads(IC<tb>{}, kfb); }
-      if constexpr (i == 2) s_mm(IC<tb>{}, IC<0>{}, kfb);
-      if constexpr (i == 3) s_mm(IC<ta>{}, IC<1>{}, kfa);
-      if constexpr (i == 4) s_mm(IC<tb>{}, IC<1>{}, kfb);
+    if constexpr (s == 0) {
+      if constexpr (k == -1) {
+        ctx_scale_block();
+        dump16(0, eo[0]); dump16(16, eo[1]); dump16(32, eo[2]);
+      }
+      if constexpr (k == 0) pack_block(co, 1.0f, ch0, ch1, cl0, cl1);
+      if constexpr (k == 1) ctx_store();
+      if constexpr (k >= 2 && k <= 5) epi_qk_quad(IC<0>{}, IC<(k >= 2 && k <= 5) ? k - 2 : 0>{}, ph);
+      if constexpr (k == 6) epi_q_finish();
+      if constexpr (k >= 7 && k <= 10) epi_qk_quad(IC<1>{}, IC<(k >= 7 && k <= 10) ? k - 7 : 0>{}, ph);
+      if constexpr (k == 11) epi_k_finish();
+      if constexpr (k >= 12 && k <= 15) epi_v_quad(IC<(k >= 12 && k <= 15) ? k - 12 : 0>{}, ph);
     }
-    if constexpr (s == 2) {
-      if constexpr (i == 0) { e_reads(IC<0>{}, kfa); e_reads(IC<1>{}, kfb); }
-      if constexpr (i == 1) m_mm(IC<0>{}, IC<0>{}, kfa);
-      if constexpr (i == 2) m_mm(IC<1>{}, IC<0>{}, kfb);
-      if constexpr (i == 3) m_mm(IC<0>{}, IC<1>{}, kfa);
-      if constexpr (i == 4) m_mm(IC<1>{}, IC<1>{}, kfb);
-      if constexpr (i == 5) op_W(IC<0>{});
-      if constexpr (i == 6) op_W(IC<1>{});
+    if constexpr (s == 1 || s == 2) {
+      constexpr int ta = 2 * (s - 1), tb = ta + 1;
+      if constexpr (k == -1) { k_reads(IC<ta>{}, IC<0>{}, kfa); k_reads(IC<tb>{}, IC<0>{}, kfb); }
+      if constexpr (k == 1) { k_reads(IC<ta>{}, IC<1>{}, kfa); k_reads(IC<tb>{}, IC<1>{}, kfb); }
+      if constexpr (k >= 2 && k <= 13) {
+        constexpr int i = (k >= 2 && k <= 13) ? (k - 2) / 2 : 0;
+        if constexpr ((k & 1) == 0) s_mm1(IC<ta>{}, IC<i>{}, kfa);
+        else s_mm1(IC<tb>{}, IC<i>{}, kfb);
+      }
     }
-    if constexpr (s >= 3 && s <= 5) {
-      constexpr int m = s - 1, q = s - 3;
-      if constexpr (i == 0) { e_reads(IC<m>{}, kfa); g_reads(IC<q>{}); }
-      if constexpr (i == 1) m_mm(IC<m>{}, IC<0>{}, kfa);
-      if constexpr (i == 2) m_mm(IC<m>{}, IC<1>{}, kfa);
-      if constexpr (i == 3) g_fma(IC<q>{});
-      if constexpr (i == 5) op_W(IC<m>{});
+    if constexpr (s == 3) {
+      if constexpr (k == -1) {
+        e_reads(IC<0>{}, kfa); e_reads(IC<1>{}, kfb);
+        dump16(48, sacc[0]); dump16(64, sacc[1]); dump16(80, sacc[2]); dump16(96, sacc[3]);  // raw S^T
+      }
+      if constexpr (k >= 2 && k <= 13) {
+        constexpr int i = (k >= 2 && k <= 13) ? (k - 2) / 2 : 0;
+        if constexpr ((k & 1) == 0) m_mm1(IC<0>{}, IC<i>{}, kfa);
+        else m_mm1(IC<1>{}, IC<i>{}, kfb);
+      }
+      if constexpr (k == 15) op_W(IC<0>{});
+      if constexpr (k == 17) op_W(IC<1>{});
     }
-    if constexpr (s == 6) {
-      if constexpr (i == 0) g_reads(IC<3>{});
-      if constexpr (i == 1) g_fma(IC<3>{});
-      if constexpr (i == 2) {
-        // key mask (log2 domain comes later): this lane + its partner (lane ^ 32) hold one query's scores
+    if constexpr (s >= 4 && s <= 6) {
+      constexpr int m = s - 2, q = s - 4;
+      if constexpr (k == -1) { e_reads(IC<m>{}, kfa); g_reads(IC<q>{}); }
+      if constexpr (k >= 2 && k <= 7) m_mm1(IC<m>{}, IC<(k >= 2 && k <= 7) ? k - 2 : 0>{}, kfa);
+      if constexpr (k >= 8 && k <= 11) g_fma4(IC<q>{}, IC<(k >= 8 && k <= 11) ? 4 * (k - 8) : 0>{});
+      if constexpr (k == 14) op_W(IC<m>{});
+    }
+    if constexpr (s == 7) {
+      if constexpr (k == -1) g_reads(IC<3>{});
+      if constexpr (k >= 2 && k <= 5) g_fma4(IC<3>{}, IC<(k >= 2 && k <= 5) ? 4 * (k - 2) : 0>{});
+      if constexpr (k == 6) {
+        dump16(112, sacc[0]); dump16(128, sacc[1]); dump16(144, sacc[2]); dump16(160, sacc[3]);  // S^T with the band
+        // key mask: this lane + its partner (lane ^ 32) hold one query's scores
         if (len < LP) {
 #pragma unroll
           for (int t = 0; t < T; ++t)
@@ -501,91 +564,63 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
               sacc[t][r] = sc;
             }
         }
+        mt = -INFINITY;
       }
-      if constexpr (i == 3) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[t][r]);
-        mt = m;
-      }
-      if constexpr (i == 4) {
+      if constexpr (k >= 7 && k <= 14) {  // row maximum, eight scores per slot in element order
+        constexpr int e0 = (k >= 7 && k <= 14) ? 8 * (k - 7) : 0;
         float m = mt;
 #pragma unroll
-        for (int t = 2; t < T; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[t][r]);
+        for (int e = e0; e < e0 + 8; ++e) m = fmaxf(m, sacc[e >> 4][e & 15]);
         mt = m;
       }
-      if constexpr (i == 5) {
+      if constexpr (k == 15) {
         mt = pair_max(mt);
         nm = __builtin_fmaf(-mt, s_scale, 10.0f);  // + log2(PS): p' = PS * 2^((u - m) * s_scale)
         static_assert(PS == 1024.0f, "exponent offset above is log2(PS)");
         psum = 0.f;
       }
     }
-    if constexpr (s == 7 || s == 8) {
-      constexpr int st[8] = {0, 5, 10, 15, 20, 24, 28, 32};
-      exp_range(2 * (s - 7), st[i], st[i + 1]);
-      if constexpr (s == 8 && i == 6) l_run = pair_sum(psum);  // carries the factor PS
+    if constexpr (s == 8 || s == 9) {
+      if constexpr (k >= 0 && k <= 15) exp_range(2 * (s - 8), 2 * (k >= 0 ? k : 0), 2 * (k >= 0 ? k : 0) + 2);
+      if constexpr (s == 9 && k == 16) l_run = pair_sum(psum);  // carries the factor PS
     }
-    if constexpr (s == 9 || s == 10) {
-      constexpr int ta = 2 * (s - 9), tb = ta + 1;
-      if constexpr (i == 0) pv_prep(IC<ta>{}, IC<0>{});
-      if constexpr (i == 1) { pv_mm(IC<(ta == 0) ? 1 : 0>{}); pv_prep(IC<ta>{}, IC<1>{}); }
-      if constexpr (i == 2) { pv_mm(IC<0>{}); pv_prep(IC<tb>{}, IC<0>{}); }
-      if constexpr (i == 3) { pv_mm(IC<0>{}); pv_prep(IC<tb>{}, IC<1>{}); }
-      if constexpr (i == 4) pv_mm(IC<0>{});
-    }
-    if constexpr (s == 11) {
-      // ctx[token row][head block] = O^T[d][query] / l_run at the ctx image's scale (attention_img.hip: flush_ctx)
-      if constexpr (i == 1) {
-        const float onorm = p.ctx_scale / (p.v_scale * l_run);
-        float o[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = oacc[r] * onorm;
-        pack_block(o, 1.0f, ch0, ch1, cl0, cl1);
+    if constexpr (s == 10 || s == 11) {
+      constexpr int ta = 2 * (s - 10);
+      if constexpr (k == -1) {
+        if constexpr (s == 10) { dump16(176, sacc[0]); dump16(192, sacc[1]); dump16(208, sacc[2]); dump16(224, sacc[3]); }  // probabilities
+        pv_prep(IC<ta>{}, IC<0>{});
       }
-      if constexpr (i == 2) {
-        const int l = 32 * wq + l31;
-        const int row = row0 + l;
-        const unsigned voff = l < nrows ? (unsigned)((((row >> 5) * H * 8 + 2 * half) * 32 + (row & 31)) * 16) : 0xFFFFFF00u;
-        const int hoff = ahead * 4096;
-        const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0xFFFFFF00u, 0x00020000);
-        if (!(FDMI_SA_DBG & 4)) {
-          __builtin_amdgcn_raw_buffer_store_b128(ch0, rsc, (int)voff, hoff, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(ch1, rsc, (int)voff, hoff + 512, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(cl0, rsc, (int)voff, hoff + 4 * 512, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(cl1, rsc, (int)voff, hoff + 5 * 512, 0);
-          store_guard(ch0, ch1);
-          store_guard(cl0, cl1);
-        }
+      if constexpr (k >= 1 && k <= 16) {
+        constexpr int kk = (k >= 1 && k <= 16) ? k - 1 : 0, u = kk / 4, j = kk % 4;  // unit u = (tile ta + u / 2, k16 step u % 2)
+        if constexpr (j < 3) pv_mm1(IC<j>{}, IC<(ta == 0 && u == 0) ? 1 : 0>{});
+        else if constexpr (u < 3) pv_prep(IC<ta + (u + 1) / 2>{}, IC<(u + 1) % 2>{});
       }
     }
   };
-  // the attention chunks in front of projection group `gap` (gap 6: behind the last group).  d_model 384: one slice per stage,
-  // chunk = gap.  d_model 192 (six stages, two slices A, B per stage, NOT interleaved with each other: they share registers):
-  // gaps 0-2 run A's chunks 0..5 two at a time, gap 3 A's chunk 6 and B's chunk 0, gaps 4-6 B's chunks 1..6 two at a time.
-  auto attn_gap = [&](auto KT, auto GAP, int ahead) __attribute__((always_inline)) {
-    constexpr int kt = decltype(KT)::value, gap = decltype(GAP)::value;
+  // the attention work behind projection MFMA `slot` of stage kt.  d_model 384: one slice per stage, slot = slice slot.  d_model 192
+  // (six stages, two slices A, B per stage, NOT interleaved with each other: they share registers): slots 0-8 run A's slots two
+  // at a time (its slot -1 in front of the stage), slots 9-17 run B's (its slot -1 with A's last).
+  auto attn_at = [&](auto KT, auto SLOT, int ph) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value, slot = decltype(SLOT)::value;
     if constexpr (SPS == 1) {
-      attn_chunk(IC<kt>{}, IC<gap>{}, ahead);
+      attn_slot(IC<kt>{}, IC<slot>{}, ph);
     } else {
       constexpr int a = 2 * kt, b = 2 * kt + 1;
-      if constexpr (gap < 3) { attn_chunk(IC<a>{}, IC<2 * gap>{}, ahead); attn_chunk(IC<a>{}, IC<2 * gap + 1>{}, ahead); }
-      if constexpr (gap == 3) { attn_chunk(IC<a>{}, IC<6>{}, ahead); attn_chunk(IC<b>{}, IC<0>{}, ahead); }
-      if constexpr (gap > 3) { attn_chunk(IC<b>{}, IC<2 * gap - 7>{}, ahead); attn_chunk(IC<b>{}, IC<2 * gap - 6>{}, ahead); }
+      if constexpr (slot == -1) attn_slot(IC<a>{}, IC<-1>{}, ph);
+      if constexpr (slot >= 0 && slot <= 8) { attn_slot(IC<a>{}, IC<2 * slot>{}, ph); attn_slot(IC<a>{}, IC<2 * slot + 1>{}, ph); }
+      if constexpr (slot == 8) attn_slot(IC<b>{}, IC<-1>{}, ph);
+      if constexpr (slot >= 9) { attn_slot(IC<b>{}, IC<2 * (slot - 9)>{}, ph); attn_slot(IC<b>{}, IC<2 * (slot - 9) + 1>{}, ph); }
     }
   };
 
   // ================================================================ the item stream.  Item i = (sequence i / H of this workgroup,
-  // head i % H); iteration i runs the projection of item i fused with the attention of item i - 1 -- across sequences too: the
-  // hidden state of the next sequence replaces the current one IN PLACE, k-tile by k-tile, each right behind its last use in the
-  // sequence's last head (twelve stages before its first use).  Iteration 0's attention works on garbage (its stores are dropped:
-  // nrows = 0); the last iteration has no projection (wave-uniform branches around its stages' projection parts).
-  // One loop body = one register allocation: with separate code for the first / last head of a sequence hipcc moved ~200
-  // registers through scratch at every seam (44 k cycles each, profiles/r05_seq_attn_notes.log).
+  // head i % H); iteration i runs the projection of item i fused with the attention of item i - 1 (whose epilogue opens it, and whose
+  // ctx block leaves at the start of iteration i + 1) -- across sequences too: the hidden state of the next sequence replaces the
+  // current one IN PLACE, k-tile by k-tile, each right behind its last use in the sequence's last head (twelve stages before its
+  // first use).  Iteration 0's attention works on garbage (its stores are dropped: nrows = 0); the last iteration projects the last
+  // head once more for nothing -- ONE loop body without branches around the MFMAs = one register allocation: with separate code for
+  // the first / last head of a sequence hipcc moved ~200 registers through scratch at every seam (44 k cycles each,
+  // profiles/r05_seq_attn_notes.log).
   int seq = blockIdx.x;
   if (seq >= p.B) {
     FD_WAIT_VM(0);
@@ -596,69 +631,86 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) { load_h_kt(KT, p_row0); });
 #pragma unroll
   for (int j = 0; j < 3; ++j) acc[j] = zero16;
+  oacc = zero16;
   issue_w();
   issue_w();
   issue_w();
-  int head = 0;
+  int head = 0;       // head of the item being projected
+  int prev_head = 0;  // ... of the item before it, whose attention this iteration runs
+  int prev_seq = seq, prev_row0 = p_row0;
   for (int it = 0; it <= nitems; ++it) {
-    const bool do_proj = it < nitems;
+    const bool real = it < nitems;
     // vector-memory bookkeeping of the stage-top waits: 0 plain (the 6 pieces of the two younger stages); 1 this iteration
     // re-loads the hidden state (4 more loads per stage); 2 the iteration after such a one
-    const bool reload = do_proj && head == H - 1 && seq + (int)gridDim.x < p.B;
+    const bool reload = real && head == H - 1 && seq + (int)gridDim.x < p.B;
     const int n_row0 = reload ? sload(p.seq_row0, seq + (int)gridDim.x) : 0;
-    const bool after_reload = do_proj && head == 0 && it > 0;
+    const bool after_reload = real && head == 0 && it > 0;
     static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
       constexpr int kt = decltype(KT)::value;
       FD_STAMP(kt);
-      if (do_proj) {
-        // this stage landed: loads retire in order, so it is complete once no more loads are outstanding than were issued behind
-        // it (stores in flight only make the wait conservative).  Behind stage s: the 3 pieces of s+1 and of s+2, and -- while
-        // the hidden state is being re-loaded -- the 4 loads issued at the end of stages s-2 and s-1
-        if (reload) {
-          if constexpr (kt == 0) FD_WAIT_VM(6);
-          else if constexpr (kt == 1) FD_WAIT_VM(10);
-          else FD_WAIT_VM(14);
-        } else if (after_reload) {
-          if constexpr (kt == 0) FD_WAIT_VM(14);
-          else if constexpr (kt == 1) FD_WAIT_VM(10);
-          else FD_WAIT_VM(6);
-        } else {
-          FD_WAIT_VM(6);
-        }
-        barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
-        issue_w();
-        proj_top();
+      // this stage landed: loads retire in order, so it is complete once no more loads are outstanding than were issued behind it
+      // (stores in flight only make the wait conservative).  Behind stage s: the 3 pieces of s+1 and of s+2, and -- while the hidden
+      // state is being re-loaded -- the 4 loads issued at the end of stages s-2 and s-1
+      if (reload) {
+        if constexpr (kt == 0) FD_WAIT_VM(6);
+        else if constexpr (kt == 1) FD_WAIT_VM(10);
+        else FD_WAIT_VM(14);
+      } else if (after_reload) {
+        if constexpr (kt == 0) FD_WAIT_VM(14);
+        else if constexpr (kt == 1) FD_WAIT_VM(10);
+        else FD_WAIT_VM(6);
       } else {
-        if constexpr (kt == 0) barrier_keep_vm();  // K / V of the last head are complete
+        FD_WAIT_VM(6);
+      }
+      barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
+      issue_w();
+      proj_top();
+      if constexpr (kt == 0) {  // the finished head's accumulators leave the matrix registers: its epilogue runs under this stage
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          eo[j] = acc[j];
+          acc[j] = zero16;
+        }
       }
       FD_SB();
-      static_for<0, 6>([&](auto G) __attribute__((always_inline)) {
-        attn_gap(KT, G, head == 0 ? H - 1 : head - 1);
+      attn_at(KT, IC<-1>{}, prev_head);
+      FD_SB();
+      static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
+        proj_mfma(KT, K);
         FD_SB();
-        if (do_proj) proj_group(KT, G);
+        attn_at(KT, K, prev_head);
         FD_SB();
       });
-      attn_gap(KT, IC<6>{}, head == 0 ? H - 1 : head - 1);
-      FD_SB();
+      if constexpr (kt == 0) {
+        // the attention that starts now (item it - 1) may belong to a new sequence
+        a_head = prev_head;
+        if (prev_head == 0 && it > 0) {
+          row0 = prev_row0;
+          nrows = sload(p.seq_row0, prev_seq + 1) - row0;
+          Lb = sload(p.nrow, prev_seq);
+          len = sload(p.lens, prev_seq);
+        }
+      }
       if (reload) load_h_kt(KT, n_row0);
       FD_SB();
-      if (do_proj) ++pos;
+      ++pos;
     });
-    if (do_proj) epilogue(head);
     ++slot;
-    // the attention that starts now belongs to the sequence just projected
-    if (do_proj && head == 0) {
-      row0 = p_row0;
-      nrows = sload(p.seq_row0, seq + 1) - row0;
-      Lb = sload(p.nrow, seq);
-      len = sload(p.lens, seq);
-    }
-    if (++head == H) {
+    prev_head = head;
+    prev_seq = seq;
+    prev_row0 = p_row0;
+    if (real && ++head == H) {
       head = 0;
-      seq += (int)gridDim.x;
-      p_row0 = n_row0;
+      if (seq + (int)gridDim.x < p.B) {
+        seq += (int)gridDim.x;
+        p_row0 = n_row0;
+      }
     }
   }
+  // the last item's ctx block
+  ctx_scale_block();
+  pack_block(co, 1.0f, ch0, ch1, cl0, cl1);
+  ctx_store();
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 #undef FD_STAMP
 #undef FD_SB
