@@ -696,7 +696,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     // q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): q, k and v never reach HBM
     static const int fuse_attn_env = [] { const char* e = getenv("FDMI_FUSE_ATTN"); return e ? atoi(e) : -1; }();
     const int fuse_attn = m->fuse_attn >= 0 ? m->fuse_attn : fuse_attn_env;
-    const bool fused_attn = lw.wsa_i.p && fuse_attn > 0 /* (auto: off until the kernel beats the two-kernel path) */ && !mode.kmask && !m->split_qkv &&
+    const bool fused_attn = lw.wsa_i.p && fuse_attn != 0 && (fuse_attn > 0 || !m->varlen) && !mode.kmask && !m->split_qkv &&
                             seq_attn_supported(d, c.n_heads, L, c.max_pos) && (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
     if (fused_attn) {
       SeqAttnArgs a;

@@ -33,7 +33,8 @@
 #include "img_common.h"
 
 #ifndef FDMI_SA_SCHED
-#define FDMI_SA_SCHED 1  // 1: the stage's instruction order is dictated with sched_group_barrier (MFMA : LDS read : VALU pattern)
+#define FDMI_SA_SCHED 0  // 0: the source order of the slots is the schedule (sched_barrier between them); 1: the slots' order only holds for
+                         // the MFMAs, everything else of a stage is dealt out evenly behind them with sched_group_barrier
 #endif
 #ifndef FDMI_SA_DBG
 #define FDMI_SA_DBG 0  // ablation builds (wrong results): 1 = no attention slices, 2 = no projection MFMAs, 4 = no ctx stores
@@ -181,19 +182,19 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   // ---- the weight stream: positions (sequence, head, k-tile) of this workgroup, one 12 KiB stage each; the stream does not stop at
   // a sequence's end (the next sequence's first stages are requested during the last head)
   const int nseq = (p.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = (nseq * H + 1) * NKT;  // (the last iteration projects the last head once more: see the item stream)
-  int pos = 0;   // position being computed
-  int wsrc = 0;  // (head, k-tile) index of the next position to request, 0 .. H NKT - 1
-  int wreq = 0;  // positions requested so far
+  int pos = 0;     // position being computed
+  int w_src = 0;   // byte offset of the next position to request inside the weight image: (head, k-tile) wraps after the last head
+  int w_slot = 0;  // byte offset of the ring slot it goes to
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.wimg), 0, H * NKT * KT_BYTES, 0x00020000);
-  auto issue_w = [&]() __attribute__((always_inline)) {  // past the end: the last position again (lands in a free slot, never read)
-    const lds_ptr_t dst = (lds_ptr_t)(Wr) + __builtin_amdgcn_readfirstlane((wreq & (NST - 1)) * KT_BYTES);
-    const int so = __builtin_amdgcn_readfirstlane(wsrc * KT_BYTES);
+  // (the stream simply runs on past the workgroup's last position: what it requests there lands in free slots and is never read)
+  auto issue_w = [&]() __attribute__((always_inline)) {
+    const lds_ptr_t dst = (lds_ptr_t)(Wr) + __builtin_amdgcn_readfirstlane(w_slot);
+    const int so = __builtin_amdgcn_readfirstlane(w_src);
 #pragma unroll
     for (int k = 0; k < 3; ++k) dma16(rs_w, dst + (wq + 4 * k) * 1024, lane * 16, so + (wq + 4 * k) * 1024);
-    ++wreq;
-    if (wreq < total) wsrc = wsrc + 1 == H * NKT ? 0 : wsrc + 1;
+    w_src = w_src + KT_BYTES == H * NKT * KT_BYTES ? 0 : w_src + KT_BYTES;
+    w_slot = w_slot + KT_BYTES == NST * KT_BYTES ? 0 : w_slot + KT_BYTES;
   };
 
   // ---- per-sequence state
@@ -249,12 +250,14 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) dst[j] = __builtin_bit_cast(f16x8, lds_u128(wb + (unsigned)(unit * 1536 + j * 512)));
   };
-  auto proj_top = [&]() __attribute__((always_inline)) {
+  auto proj_first = [&]() __attribute__((always_inline)) {  // (the stream's very first stage; afterwards every stage finds its first planes in place)
     wb = w_rd + (unsigned)((pos & (NST - 1)) * KT_BYTES);
     rd_w(Xw, 0);
     rd_w(Yw, 4);
   };
-  // MFMA k = 3 g + j of the stage: group g, accumulator j (q | k in the swapped form, v in the normal form: lane = feature)
+  // MFMA k = 3 g + j of the stage: group g, accumulator j (q | k in the swapped form, v in the normal form: lane = feature).  The
+  // planes of k16 step 0 of the NEXT stage (which has landed: see the stage-top wait) are requested as soon as X / Y are free, so a
+  // stage's first MFMA does not wait for an LDS round trip behind the barrier.
   auto proj_mfma = [&](auto KT, auto K) __attribute__((always_inline)) {
     constexpr int kt = decltype(KT)::value, k = decltype(K)::value, g = k / 3, j = k % 3;
     if (FDMI_SA_DBG & 2) return;
@@ -264,6 +267,11 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf, w, acc[2], 0, 0, 0);
     if constexpr (k == 5) rd_w(Xw, 2);  // X is free: the hi plane of k16 step 1
     if constexpr (k == 8) rd_w(Yw, 6);  // Y is free: the lo plane of k16 step 1
+    if constexpr (k == 14) {            // X is free: the next stage's hi plane of step 0
+      wb = w_rd + (unsigned)(((pos + 1) & (NST - 1)) * KT_BYTES);
+      rd_w(Xw, 0);
+    }
+    if constexpr (k == 17) rd_w(Yw, 4);  // Y is free: the next stage's lo plane of step 0
   };
 
   // ================================================================ the attention of one head, software pipelined into the 18 MFMA
@@ -285,11 +293,11 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   u32x4 kfa[4], kfb[4];  // K fragments of two S^T tiles / the table rows of two band tiles: [hi c0, hi c1, lo c0, lo c1]
   float gth[16];         // gathered band values
   float psum = 0.f;
-  f16x8 pvh, pvl, pph, ppl;  // V^T and P operands of the next P V triple
+  f16x8 pvh[2], pvl[2], pph[2], ppl[2];  // V^T and P operands of the P V triple in flight and of the next one
   u32x4 ch0, ch1, cl0, cl1;  // the packed ctx block
   float co[16];              // ... and its values
   unsigned eHh[4][2], eLo[4][2];  // split halves of the epilogue block being assembled
-  int a_head = 0;  // head of the attention in flight (the ctx block of stage 0 belongs to it)
+  int a_head = 0, c_head = 0, c_row0 = 0, c_nrows = 0;  // head of the attention in flight; (head, first row, rows) of the ctx block that leaves in stage 2
 
   auto split_quad = [&](auto Q, const float (&o)[4]) __attribute__((always_inline)) {
     constexpr int q = decltype(Q)::value;
@@ -306,17 +314,29 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     }
   };
   // epilogue of the projected head `ph`, piece by piece (same arithmetic as gemm_img.hip's q | k and v^T epilogues):
-  auto epi_qk_quad = [&](auto J, auto Q, int ph) __attribute__((always_inline)) {  // J: 0 q, 1 k; quad Q of the lane's 16 features
-    constexpr int j = decltype(J)::value, q = decltype(Q)::value;
-    // (read through an integer LDS address: behind a pointer derived from `smem` hipcc assumes that the read may alias the LDS-DMA
-    // writes in flight and waits for the whole weight stream to land)
+  // the head's bias values are requested a few slots ahead of their first use (read at the point of use, every quad waited ~150
+  // cycles for its LDS round trip: stage 0 took 3.8 k cycles, profiles/r05_seq_attn_notes.log)
+  u32x4 bqk[2][4];  // [q | k][quad]: this lane's four bias values of the quad, at the image's scale
+  float bvv = 0.f;
+  auto bias_reads = [&](auto J, int ph) __attribute__((always_inline)) {  // J: 0 q, 1 k, 2 v
+    constexpr int j = decltype(J)::value;
     int ln;  // (an opaque copy of the lane index: see ctx_store)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    const u32x4 braw = lds_u128(par_base + (unsigned)((j * D + ph * 32 + 8 * q) * 4) + (unsigned)((ln >> 5) * 16));
+    // (read through integer LDS addresses: behind a pointer derived from `smem` hipcc assumes that the read may alias the LDS-DMA
+    // writes in flight and waits for the whole weight stream to land)
+    if constexpr (j < 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bqk[j][q] = lds_u128(par_base + (unsigned)((j * D + ph * 32 + 8 * q) * 4) + (unsigned)((ln >> 5) * 16));
+    } else {
+      bvv = lds_f32(par_base + (unsigned)((2 * D + ph * 32) * 4) + (unsigned)((ln & 31) * 4));
+    }
+  };
+  auto epi_qk_quad = [&](auto J, auto Q) __attribute__((always_inline)) {  // J: 0 q, 1 k; quad Q of the lane's 16 features
+    constexpr int j = decltype(J)::value, q = decltype(Q)::value;
     const float oss = j == 0 ? oss_q : oss_k;
     float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(eo[j][4 * q + e], oss, __builtin_bit_cast(float, (unsigned)braw[e]));
+    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(eo[j][4 * q + e], oss, __builtin_bit_cast(float, (unsigned)bqk[j][q][e]));
     split_quad(Q, o);
   };
   auto epi_q_finish = [&]() __attribute__((always_inline)) {
@@ -342,11 +362,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   };
   // v (normal form): lane = feature d = l31, register r = 4 q + e <-> key 8 q + 4 half + e of the wave's key block: a quad is one
   // 8-byte unit 2 q + half of the block's feature row (hi), + 8 (lo), stored at unit ^ vt_swz(d)
-  auto epi_v_quad = [&](auto Q, int ph) __attribute__((always_inline)) {
+  auto epi_v_quad = [&](auto Q) __attribute__((always_inline)) {
     constexpr int q = decltype(Q)::value;
-    int ln;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    const float bz = lds_f32(par_base + (unsigned)((2 * D + ph * 32) * 4) + (unsigned)((ln & 31) * 4));
+    const float bz = bvv;
     const float o[4] = {__builtin_fmaf(eo[2][4 * q + 0], oss_v, bz), __builtin_fmaf(eo[2][4 * q + 1], oss_v, bz),
                         __builtin_fmaf(eo[2][4 * q + 2], oss_v, bz), __builtin_fmaf(eo[2][4 * q + 3], oss_v, bz)};
     split_quad(Q, o);
@@ -374,10 +392,10 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     const int l = 32 * wq + (ln & 31);
-    const int row = row0 + l;
+    const int row = c_row0 + l;
     unsigned voff = (unsigned)((((row >> 5) * H * 8 + 2 * (ln >> 5)) * 32 + (row & 31)) * 16);
-    voff = l < nrows ? voff : 0xFFFFFF00u;
-    const int hoff = a_head * 4096;
+    voff = l < c_nrows ? voff : 0xFFFFFF00u;
+    const int hoff = c_head * 4096;
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0xFFFFFF00u, 0x00020000);
     if (!(FDMI_SA_DBG & 4)) {
       __builtin_amdgcn_raw_buffer_store_b128(ch0, rsc, (int)voff, hoff, 0);
@@ -400,6 +418,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     const f16x8 a = __builtin_bit_cast(f16x8, kf[j == 2 ? 2 + c : c]);
     const f16x8& b = j == 1 ? ql[c] : qh[c];
     sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, i == 0 ? zero16 : sacc[t], 0, 0, 0);
+    // (the scores are VALU operands from here on: as an accumulator in the AGPR half of the register file every later use costs a
+    // v_accvgpr_read, and this kernel is bound by its instruction count)
+    if constexpr (i == 5) asm volatile("" : "+v"(sacc[t]));
   };
   auto e_reads = [&](auto QQ, u32x4 (&e)[4]) __attribute__((always_inline)) {  // e[0] hi c0, e[1] hi c1, e[2] lo c0, e[3] lo c1 of the lane's band row
     constexpr int qq = decltype(QQ)::value;
@@ -419,6 +440,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     const f16x8 a = __builtin_bit_cast(f16x8, e[j == 1 ? 2 + c : c]);
     const f16x8& b = j == 2 ? ql[c] : qh[c];
     racc[qq & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, i == 0 ? zero16 : racc[qq & 1], 0, 0, 0);
+    if constexpr (i == 5) asm volatile("" : "+v"(racc[qq & 1]));  // (ds_write_addtid takes VGPRs: see s_mm1)
   };
   auto op_W = [&](auto QQ) __attribute__((always_inline)) {  // scratch slot qq & 1 <- racc[qq & 1]: register r of all 64 lanes lands as band rows 2 r, 2 r + 1
     constexpr int qq = decltype(QQ)::value;
@@ -455,7 +477,11 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   auto g_fma4 = [&](auto Q, auto R0) __attribute__((always_inline)) {
     constexpr int t = T - 1 - decltype(Q)::value, r0 = decltype(R0)::value;
 #pragma unroll
-    for (int r = r0; r < r0 + 4; ++r) sacc[t][r] = __builtin_fmaf(gth[r], p.r_scale, sacc[t][r]);
+    for (int r = r0; r < r0 + 4; ++r) {
+      float f = __builtin_fmaf(gth[r], p.r_scale, sacc[t][r]);
+      asm volatile("" : "+v"(f));  // (keeps the fma in this slot, see exp_range)
+      sacc[t][r] = f;
+    }
   };
   // exponentials of elements [lo, hi) of the 32 scores of tiles (tbase, tbase + 1), summed in element order
   auto exp_range = [&](int tbase, int lo, int hi) __attribute__((always_inline)) {
@@ -467,10 +493,14 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       sacc[t][r] = pexp;
       psum += pexp;
     }
+    // (a use with side effects in THIS slot: a pure chain whose first use sits in a later stage is sunk there -- the exponentials of
+    // tiles 0, 1 all ran at the top of the next stage)
+    asm volatile("" : "+v"(psum));
   };
-  // P V over key tile t, k16 step c: operands (split of eight probabilities, four 8-byte V^T units), then vh ph | vl ph | vh pl
-  auto pv_prep = [&](auto TT, auto CC) __attribute__((always_inline)) {
-    constexpr int t = decltype(TT)::value, c = decltype(CC)::value;
+  // P V over key tile t, k16 step c: operands (split of eight probabilities, four 8-byte V^T units) into buffer g & 1 of unit
+  // g = 2 t + c, prepared while the unit before it multiplies; then vh ph | vl ph | vh pl
+  auto pv_prep = [&](auto G) __attribute__((always_inline)) {
+    constexpr int g = decltype(G)::value, t = g / 2, c = g % 2, bf = g & 1;
     u32x4 phu, plu;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -479,8 +509,8 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       phu[j] = hv;
       plu[j] = lv;
     }
-    pph = __builtin_bit_cast(f16x8, phu);
-    ppl = __builtin_bit_cast(f16x8, plu);
+    pph[bf] = __builtin_bit_cast(f16x8, phu);
+    ppl[bf] = __builtin_bit_cast(f16x8, plu);
     typedef const __attribute__((address_space(3))) u32x2* lds_cu64_t;
     const unsigned blk = v_rd + (unsigned)(t * 4096);
     const int ua = 4 * c + half;
@@ -488,14 +518,15 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     const u32x2 vh1 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)(((ua + 2) ^ vsz) << 3));
     const u32x2 vl0 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)(((ua + 8) ^ vsz) << 3));
     const u32x2 vl1 = *(lds_cu64_t)(unsigned long long)(blk + (unsigned)(((ua + 10) ^ vsz) << 3));
-    pvh = __builtin_bit_cast(f16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
-    pvl = __builtin_bit_cast(f16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
+    pvh[bf] = __builtin_bit_cast(f16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
+    pvl[bf] = __builtin_bit_cast(f16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
   };
-  auto pv_mm1 = [&](auto J, auto FIRST) __attribute__((always_inline)) {  // J: 0 vh ph | 1 vl ph | 2 vh pl
-    constexpr int j = decltype(J)::value;
-    const f16x8& a = j == 1 ? pvl : pvh;
-    const f16x8& b = j == 2 ? ppl : pph;
-    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, (j == 0 && decltype(FIRST)::value) ? zero16 : oacc, 0, 0, 0);
+  auto pv_mm1 = [&](auto G, auto J) __attribute__((always_inline)) {  // J: 0 vh ph | 1 vl ph | 2 vh pl
+    constexpr int g = decltype(G)::value, j = decltype(J)::value, bf = g & 1;
+    const f16x8& a = j == 1 ? pvl[bf] : pvh[bf];
+    const f16x8& b = j == 2 ? ppl[bf] : pph[bf];
+    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, (g == 0 && j == 0) ? zero16 : oacc, 0, 0, 0);
+    if constexpr (g == 7 && j == 2) asm volatile("" : "+v"(oacc));
   };
 
   // slot k (0..17; -1: in front of the stage's first projection MFMA) of attention slice s.  `ph`: the head whose projection
@@ -504,17 +535,18 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     constexpr int s = decltype(S)::value, k = decltype(K)::value;
     if (FDMI_SA_DBG & 1) return;
     if constexpr (s == 0) {
+      // (q and k here: the S^T tiles of the next stage want them; v and the ctx block of the head before ride in the two S^T
+      // stages, which are light on VALU work)
       if constexpr (k == -1) {
-        ctx_scale_block();
+        bias_reads(IC<0>{}, ph);
         dump16(0, eo[0]); dump16(16, eo[1]); dump16(32, eo[2]);
       }
-      if constexpr (k == 0) pack_block(co, 1.0f, ch0, ch1, cl0, cl1);
-      if constexpr (k == 1) ctx_store();
-      if constexpr (k >= 2 && k <= 5) epi_qk_quad(IC<0>{}, IC<(k >= 2 && k <= 5) ? k - 2 : 0>{}, ph);
+      if constexpr (k == 0) bias_reads(IC<1>{}, ph);
+      if constexpr (k == 1) bias_reads(IC<2>{}, ph);
+      if constexpr (k >= 2 && k <= 5) epi_qk_quad(IC<0>{}, IC<(k >= 2 && k <= 5) ? k - 2 : 0>{});
       if constexpr (k == 6) epi_q_finish();
-      if constexpr (k >= 7 && k <= 10) epi_qk_quad(IC<1>{}, IC<(k >= 7 && k <= 10) ? k - 7 : 0>{}, ph);
-      if constexpr (k == 11) epi_k_finish();
-      if constexpr (k >= 12 && k <= 15) epi_v_quad(IC<(k >= 12 && k <= 15) ? k - 12 : 0>{}, ph);
+      if constexpr (k >= 8 && k <= 11) epi_qk_quad(IC<1>{}, IC<(k >= 8 && k <= 11) ? k - 8 : 0>{});
+      if constexpr (k == 12) epi_k_finish();
     }
     if constexpr (s == 1 || s == 2) {
       constexpr int ta = 2 * (s - 1), tb = ta + 1;
@@ -524,6 +556,14 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
         constexpr int i = (k >= 2 && k <= 13) ? (k - 2) / 2 : 0;
         if constexpr ((k & 1) == 0) s_mm1(IC<ta>{}, IC<i>{}, kfa);
         else s_mm1(IC<tb>{}, IC<i>{}, kfb);
+      }
+      if constexpr (s == 1) {  // the v part of the projection epilogue (V^T is not read before stage 10)
+        if constexpr (k == 4 || k == 8 || k == 12 || k == 16) epi_v_quad(IC<(k == 4 || k == 8 || k == 12 || k == 16) ? k / 4 - 1 : 0>{});
+      }
+      if constexpr (s == 2) {  // the ctx block of the head before
+        if constexpr (k == 0) ctx_scale_block();
+        if constexpr (k == 6) pack_block(co, 1.0f, ch0, ch1, cl0, cl1);
+        if constexpr (k == 12) ctx_store();
       }
     }
     if constexpr (s == 3) {
@@ -571,6 +611,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
         float m = mt;
 #pragma unroll
         for (int e = e0; e < e0 + 8; ++e) m = fmaxf(m, sacc[e >> 4][e & 15]);
+        asm volatile("" : "+v"(m));  // (keeps the maxima in this slot, see exp_range)
         mt = m;
       }
       if constexpr (k == 15) {
@@ -583,17 +624,17 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     if constexpr (s == 8 || s == 9) {
       if constexpr (k >= 0 && k <= 15) exp_range(2 * (s - 8), 2 * (k >= 0 ? k : 0), 2 * (k >= 0 ? k : 0) + 2);
       if constexpr (s == 9 && k == 16) l_run = pair_sum(psum);  // carries the factor PS
+      if constexpr (s == 9 && k == 17) {
+        dump16(176, sacc[0]); dump16(192, sacc[1]); dump16(208, sacc[2]); dump16(224, sacc[3]);  // probabilities
+        pv_prep(IC<0>{});
+      }
     }
     if constexpr (s == 10 || s == 11) {
-      constexpr int ta = 2 * (s - 10);
-      if constexpr (k == -1) {
-        if constexpr (s == 10) { dump16(176, sacc[0]); dump16(192, sacc[1]); dump16(208, sacc[2]); dump16(224, sacc[3]); }  // probabilities
-        pv_prep(IC<ta>{}, IC<0>{});
-      }
+      constexpr int g0 = 4 * (s - 10);  // units g0 .. g0 + 3: MFMAs in slots 4 u + 1 .. 4 u + 3, the next unit's operands prepared in slot 4 u + 1
       if constexpr (k >= 1 && k <= 16) {
-        constexpr int kk = (k >= 1 && k <= 16) ? k - 1 : 0, u = kk / 4, j = kk % 4;  // unit u = (tile ta + u / 2, k16 step u % 2)
-        if constexpr (j < 3) pv_mm1(IC<j>{}, IC<(ta == 0 && u == 0) ? 1 : 0>{});
-        else if constexpr (u < 3) pv_prep(IC<ta + (u + 1) / 2>{}, IC<(u + 1) % 2>{});
+        constexpr int kk = (k >= 1 && k <= 16) ? k - 1 : 0, u = kk / 4, j = kk % 4;
+        if constexpr (j < 3) pv_mm1(IC<g0 + u>{}, IC<j>{});
+        if constexpr (j == 0 && g0 + u + 1 < 8) pv_prep(IC<(g0 + u + 1 < 8) ? g0 + u + 1 : 0>{});
       }
     }
   };
@@ -635,6 +676,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   issue_w();
   issue_w();
   issue_w();
+  FD_WAIT_VM(6);  // the first stage (and the hidden state, requested before it) landed
+  barrier_keep_vm();
+  proj_first();
   int head = 0;       // head of the item being projected
   int prev_head = 0;  // ... of the item before it, whose attention this iteration runs
   int prev_seq = seq, prev_row0 = p_row0;
@@ -648,23 +692,22 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
       constexpr int kt = decltype(KT)::value;
       FD_STAMP(kt);
-      // this stage landed: loads retire in order, so it is complete once no more loads are outstanding than were issued behind it
-      // (stores in flight only make the wait conservative).  Behind stage s: the 3 pieces of s+1 and of s+2, and -- while the hidden
-      // state is being re-loaded -- the 4 loads issued at the end of stages s-2 and s-1
+      // the NEXT stage landed (this one did a stage ago): loads retire in order, so it is complete once no more loads are
+      // outstanding than were issued behind it (stores in flight only make the wait conservative).  Behind stage s+1: the 3 pieces
+      // of s+2, and -- while the hidden state is being re-loaded -- the 4 loads issued at the end of stages s-2 and s-1
       if (reload) {
-        if constexpr (kt == 0) FD_WAIT_VM(6);
-        else if constexpr (kt == 1) FD_WAIT_VM(10);
-        else FD_WAIT_VM(14);
+        if constexpr (kt == 0) FD_WAIT_VM(3);
+        else if constexpr (kt == 1) FD_WAIT_VM(7);
+        else FD_WAIT_VM(11);
       } else if (after_reload) {
-        if constexpr (kt == 0) FD_WAIT_VM(14);
-        else if constexpr (kt == 1) FD_WAIT_VM(10);
-        else FD_WAIT_VM(6);
+        if constexpr (kt == 0) FD_WAIT_VM(11);
+        else if constexpr (kt == 1) FD_WAIT_VM(7);
+        else FD_WAIT_VM(3);
       } else {
-        FD_WAIT_VM(6);
+        FD_WAIT_VM(3);
       }
       barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
       issue_w();
-      proj_top();
       if constexpr (kt == 0) {  // the finished head's accumulators leave the matrix registers: its epilogue runs under this stage
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -677,10 +720,23 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       FD_SB();
       static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
         proj_mfma(KT, K);
-        FD_SB();
+        if constexpr (FDMI_SA_SCHED == 0) FD_SB();
         attn_at(KT, K, prev_head);
-        FD_SB();
+        if constexpr (FDMI_SA_SCHED == 0) FD_SB();
       });
+      if constexpr (FDMI_SA_SCHED != 0) {
+        // behind every MFMA (their source order stands): a few VALU, one transcendental, two scalar, one LDS read, one LDS write
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, FDMI_SA_SCHED, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        FD_SB();
+      }
       if constexpr (kt == 0) {
         // the attention that starts now (item it - 1) may belong to a new sequence
         a_head = prev_head;
@@ -690,6 +746,11 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
           Lb = sload(p.nrow, prev_seq);
           len = sload(p.lens, prev_seq);
         }
+      }
+      if constexpr (kt == (SPS == 1 ? 2 : 1)) {  // the ctx block of the head before has left: the next one belongs to the attention in flight
+        c_head = a_head;
+        c_row0 = row0;
+        c_nrows = nrows;
       }
       if (reload) load_h_kt(KT, n_row0);
       FD_SB();
@@ -708,6 +769,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     }
   }
   // the last item's ctx block
+  c_head = a_head;
+  c_row0 = row0;
+  c_nrows = nrows;
   ctx_scale_block();
   pack_block(co, 1.0f, ch0, ch1, cl0, cl1);
   ctx_store();

@@ -29,10 +29,10 @@ sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=2)
 torch.cuda.synchronize()
 lib = _binding.load()
 n0 = 5 * 8 * 64 * 6 + 4 * 64 * 8
-n = n0 + 4 * 64 * 16
+n = n0 + 4 * 64 * 16 + 16384
 buf = np.zeros(n, dtype=np.uint64)
 _binding.check(lib.fd_debug_read(h, b"stamps", buf.ctypes.data_as(C.c_void_p), 2 * n))
-a = buf[n0:].reshape(4, 64, 16).astype(np.int64)
+a = buf[n0:n0 + 4 * 64 * 16].reshape(4, 64, 16).astype(np.int64)
 for w in (0, 3):
     s = a[w]
     used = [i for i in range(64) if s[i, 0]]
