@@ -16,7 +16,8 @@ Inputs (x_T, lengths, weights, tables) are resident in HBM before the timed
 region starts.  Nothing is skipped or cached between passes.
 
 The JSON line also carries
-  roofline      the dominant kernel (QKV-projection GEMM): algorithmic FLOPs per launch /
+  roofline      the dominant kernel (the fused q|k|v projection + attention kernel; the q|k|v GEMM where that does not run):
+                algorithmic FLOPs per launch /
                 average launch duration measured live with hipEvents inside the timed
                 region (every 100th timestep is launched eagerly with an event pair per
                 kernel instead of replaying the graph), against the dense MFMA peak of the instruction
@@ -27,6 +28,7 @@ The JSON line also carries
   extras.small_batch  step time at batch 1 / 8 / 32 (the few-rows GEMM path)
   extras.c3     BASELINE config C3 through sampling.sample (the reference's published setting), Philox and default noise.
   extras.host_entry  p_sample_loop with host buffers in / out at C2, both noise modes.
+  extras.nerf   N1: the 780 sampled backbones of C3 through fd_nerf (angles -> coordinates).
 """
 import argparse
 import ctypes as C
@@ -123,6 +125,50 @@ def cpu_baseline(B, L, T, shape, steps=10, check_batch=8):
     }
 
 
+def measure_traffic(kernel_substr, args):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need separate
+    passes: MI355X_MICROARCH.md, TCC counter slots) over a 3-timestep eager run of this script, counters of the launches whose kernel
+    name contains `kernel_substr`; bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB (FETCH_SIZE reports half of wide streaming reads on gfx950,
+    same guide).  Returns (bytes or None, provenance)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    means = {}
+    tmp = tempfile.mkdtemp(prefix="fdmi_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--timesteps", "3", "--profile-every", "0", "--no-cpu-baseline",
+                   "--no-exact-f32", "--no-c5-extra", "--no-user-paths", "--no-traffic"]
+            if args.precision:
+                cmd += ["--precision", args.precision]
+            env = dict(os.environ, FDMI_NO_GRAPH="1", TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                            tot += float(row["Counter_Value"])
+                            n += 1
+            if n == 0:
+                return None, f"rocprofv3 --pmc {counter}: no launches of *{kernel_substr}* (rc {r.returncode}): {r.stderr[-200:]}"
+            means[counter] = tot / n
+        return (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0, (
+            f"measured in this run: rocprofv3 --pmc passes over 3 eager timesteps, mean per launch FETCH_SIZE {means['FETCH_SIZE']:.0f} KiB "
+            f"(doubled: gfx950 calibration), WRITE_SIZE {means['WRITE_SIZE']:.0f} KiB")
+    except Exception as e:  # a profiler problem must not take the benchmark line with it
+        return None, f"rocprofv3 passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +186,8 @@ def main():
     ap.add_argument("--profile-every", type=int, default=100)
     ap.add_argument("--no-history", action="store_true", help="do not keep the [T,B,L,F] history in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic (N=1 only)")
     ap.add_argument("--fuse-ln", type=int, default=-1, help="-1 auto (fused with f16x3), 0 off, 1 on")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM arithmetic (default: library default)")
     ap.add_argument("--no-exact-f32", action="store_true",
@@ -249,22 +297,24 @@ def main():
     hbm_bytes_step = sum(v["bytes"] * per_step_launches.get(k, RELEASED["num_hidden_layers"]) for k, v in kernels.items())
     mfma_mult = 3.0 if model.precision == "f16x3" else 1.0
     ms_step = elapsed / args.steps / T * 1e3
-    dom = kernels.get("gemm_qkv")
+    # the dominant launch: the fused q|k|v projection + attention kernel (seq_attn.hip) where it runs, else the q|k|v GEMM
+    dom_name = "qkv_attention_fused" if "qkv_attention_fused" in kernels else "gemm_qkv"
+    dom = kernels.get(dom_name)
     pinfo_key = model.precision  # (the exact-fp32 pass below switches the model)
     pinfo = PRECISION_INFO[pinfo_key]
-    traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (separate runs, see profiles/)
-        with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
-            traffic = json.load(fh).get(model.precision, {}).get("bytes")
-    except OSError:
-        pass
+    dom_kernel = ("sa::seq_attn_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, fp16 hi/lo "
+                  "split, 3x v_mfma_f32_32x32x16_f16 per product)") if dom_name == "qkv_attention_fused" else pinfo["kernel"]
+    traffic, traffic_note = None, "not measured (--no-traffic, N > 1 or another shape)"
+    if world == 1 and not args.no_traffic and (B, L) == (512, 128) and dom:
+        traffic, traffic_note = measure_traffic("seq_attn_kernel" if dom_name == "qkv_attention_fused" else
+                                                ("gemm_img_kernel<5" if model.precision == "f16x3" else "gemm_f32_kernel"), args)
     roofline = None
     if dom:
         roofline = {
-            "kernel": pinfo["kernel"],
+            "kernel": dom_kernel,
             "bound": "mfma", "achieved": dom["tflops"], "peak": pinfo["peak"], "unit": "TFLOP/s",
-            "frac": dom["tflops"] / pinfo["peak"], "traffic": traffic if (B, L) == (512, 128) else None,
-            "traffic_static": True,  # read from profiles/traffic.json (separate rocprofv3 --pmc passes of this command), not from this run
+            "frac": dom["tflops"] / pinfo["peak"], "traffic": traffic,
+            "traffic_source": traffic_note,
             "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "flops_per_launch": dom["flops"],
             "algorithmic_bytes_per_launch": dom["bytes"],
         }
@@ -284,7 +334,8 @@ def main():
         "config": {"workload": f"{args.config.upper()}: released foldingdiff_cath shape (d=384,H=12,d_ff=768,12 layers,relative_key"
                                f"{', max_position_embeddings=512' if L > 128 else ''}), "
                                f"L={L}, T={T}, batch {B}/GPU, synthetic HF-init weights, Philox noise, "
-                               f"history {'off' if args.no_history else 'in HBM'}",
+                               f"history {'off' if args.no_history else 'in HBM'}; timed through the device-resident entry fd_sample_dev "
+                               f"(x_init and the result stay in HBM; extras.host_entry times fd_sample_ex with both PCIe copies)",
                    "global_batch": B * world, "seq_len": L, "timesteps": T, "parallelism": f"batch-shard x{world}",
                    "fuse_ln": (args.fuse_ln if args.fuse_ln >= 0 else int(model.precision == "f16x3")),
                    "gemm_precision": model.precision},
@@ -425,6 +476,18 @@ def main():
             ms = (time.perf_counter() - ts) * 1e3 / 200
             sb["by_batch"][str(bs)] = {"ms_per_step": round(ms, 4), "backbones_per_s_at_T1000": round(bs / ms, 2)}
         extras["small_batch"] = sb
+        # (d) N1: the 780 backbones of C3 from angles to N / CA / C coordinates through fd_nerf (host arrays in and
+        # out, one launch, one lane per chain, fp64) -- what bin/sample.py does right behind sampling.sample
+        from foldingdiff_amd import nerf as fnerf
+        names = ["phi", "psi", "omega", "tau", "CA:C:1N", "C:1N:1CA"]  # canonical-full-angles
+        finals = [r[-1] for r in res3]
+        fnerf.build_backbones(finals, names)  # (first call: code object load)
+        tn = time.perf_counter()
+        coords = fnerf.build_backbones(finals, names)
+        dtn = time.perf_counter() - tn
+        assert len(coords) == 780 and all(np.isfinite(c).all() for c in coords)
+        extras["nerf"] = {"metric": "ms for the 780 backbones of C3 (lengths 50..127), angles -> N/CA/C coordinates, host arrays in / out (fd_nerf)",
+                          "ms": round(dtn * 1e3, 3), "backbones_per_s": round(780 / dtn, 1)}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(B, L, T, shape)
     print(json.dumps(result), flush=True)

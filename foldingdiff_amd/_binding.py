@@ -65,6 +65,8 @@ _SIGNATURES = {
     "fd_comm_destroy": (C.c_int, [_P]),
     "fd_philox_normal_dev": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P]),
     "fd_nerf": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "fd_shift_trim_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "fd_test_wrap": (C.c_int, [C.c_int, C.c_int, _P, C.c_int64, _P]),
     "fd_test_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "fd_test_gemm_ln": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_int]),
     "fd_test_gemm_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

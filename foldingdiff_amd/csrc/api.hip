@@ -696,7 +696,15 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     // q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): q, k and v never reach HBM
     static const int fuse_attn_env = [] { const char* e = getenv("FDMI_FUSE_ATTN"); return e ? atoi(e) : -1; }();
     const int fuse_attn = m->fuse_attn >= 0 ? m->fuse_attn : fuse_attn_env;
-    const bool fused_attn = lw.wsa_i.p && fuse_attn != 0 && (fuse_attn > 0 || !m->varlen) && !mode.kmask && !m->split_qkv &&
+    // auto: padded rows only, and only when the batch fills whole rounds of the CUs (one workgroup = one sequence at a time: 512
+    // sequences on 256 CUs are two full rounds, 300 would leave the second round four-fifths empty and 8 sequences would run on 8 CUs)
+    bool fused_auto = !m->varlen;
+    if (fused_auto) {
+      const int ncu = gemm_img_grid(1 << 30, 384);  // (= the CU count, rounded down to whole XCDs)
+      const int rounds = (B + ncu - 1) / ncu;
+      fused_auto = (double)B >= 0.94 * (double)rounds * ncu;
+    }
+    const bool fused_attn = lw.wsa_i.p && fuse_attn != 0 && (fuse_attn > 0 || fused_auto) && !mode.kmask && !m->split_qkv &&
                             seq_attn_supported(d, c.n_heads, L, c.max_pos) && (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
     if (fused_attn) {
       SeqAttnArgs a;
@@ -1391,20 +1399,23 @@ int fd_forward_ex(fd_model* m, const float* x, int t, const uint8_t* key_mask, c
   Workspace& w = m->ws;
   const size_t n = (size_t)B * L * c.n_features;
   hipStream_t s = m->stream;
+  // the lazily allocated buffers first: an out-of-memory return must not leave copies from this frame in flight
+  if (key_mask && !w.kmask) HIP_TRY(hipMalloc((void**)&w.kmask, (size_t)B * L));
+  if (position_ids && c.pos_type == FD_POS_ABSOLUTE && !w.pos_ids) HIP_TRY(hipMalloc((void**)&w.pos_ids, (size_t)B * L * 4));
   std::vector<int32_t> lens(B, L);  // every position is a row and a key; what is attended to is the mask's business
   HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(w.lens, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  // (a blocking copy: `lens` is a pageable vector of this frame, and the early returns below would destroy it under an
+  // asynchronous one)
+  HIP_TRY(hipMemcpy(w.lens, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice));
   StepMode mode{};
   mode.forward_only = true;
   if (key_mask) {
-    if (!w.kmask) HIP_TRY(hipMalloc((void**)&w.kmask, (size_t)B * L));
     HIP_TRY(hipMemcpyAsync(w.kmask, key_mask, (size_t)B * L, hipMemcpyHostToDevice, s));
     mode.kmask = w.kmask;
   }
   // (relative position types: the reference's embeddings add no position embedding and HF's distance uses arange, so
   // position_ids change nothing there -- modelling.py:157-166, BertSelfAttention)
   if (position_ids && c.pos_type == FD_POS_ABSOLUTE) {
-    if (!w.pos_ids) HIP_TRY(hipMalloc((void**)&w.pos_ids, (size_t)B * L * 4));
     HIP_TRY(hipMemcpyAsync(w.pos_ids, position_ids, (size_t)B * L * 4, hipMemcpyHostToDevice, s));
     mode.pos_ids = w.pos_ids;
   }
@@ -1412,7 +1423,7 @@ int fd_forward_ex(fd_model* m, const float* x, int t, const uint8_t* key_mask, c
   if (int rc = set_t(m, s, t)) return rc;
   if (int rc = run_step(m, s, mode)) return rc;
   HIP_TRY(hipMemcpyAsync(eps_out, w.eps, n * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));  // (also keeps `lens` alive until its copy is done)
+  HIP_TRY(hipStreamSynchronize(s));
   return check_flag(m);
 }
 
@@ -1632,6 +1643,49 @@ int fd_nerf(int device_id, const float* feats, const int32_t* lens, int B, int L
   N_TRY(hipDeviceSynchronize());
   N_TRY(hipMemcpy(coords_out, d_o, no * 8, hipMemcpyDeviceToHost));
 #undef N_TRY
+  cleanup();
+  return FD_OK;
+}
+
+int fd_shift_trim_dev(fd_model* m, const void* traj_dev, int rows, int B, int L, const void* lens_dev, const void* item_off_dev,
+                      const float* offset, void* out_dev, void* hip_stream) {
+  if (!m || !traj_dev || !lens_dev || !item_off_dev || !out_dev) return fail(FD_E_INVALID, "null argument");
+  if (!m->finalized) return fail(FD_E_STATE, "fd_finalize has not been called");
+  if (rows < 1 || B < 1 || L < 1) return fail(FD_E_INVALID, "rows=%d B=%d L=%d must be positive", rows, B, L);
+  if ((long long)rows * B > 0x7fffffffLL) return fail(FD_E_UNSUPPORTED, "rows x B = %lld blocks", (long long)rows * B);
+  HIP_TRY(hipSetDevice(m->device));
+  ShiftTrimArgs a;
+  memset(&a, 0, sizeof a);
+  a.traj = static_cast<const float*>(traj_dev); a.lens = static_cast<const int*>(lens_dev);
+  a.item_off = static_cast<const long long*>(item_off_dev); a.out = static_cast<float*>(out_dev);
+  a.rows = rows; a.B = B; a.L = L; a.F = m->cfg.n_features;
+  a.angle_mask = m->angle_mask;
+  a.has_offset = offset ? 1 : 0;
+  if (offset)
+    for (int f = 0; f < a.F; ++f) a.offset[f] = offset[f];
+  launch_shift_trim(a, hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream);
+  HIP_TRY(hipGetLastError());
+  return FD_OK;
+}
+
+int fd_test_wrap(int device_id, int which, const float* in, int64_t n, float* out) {
+  if (!in || !out || n < 1) return fail(FD_E_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(device_id));
+  float *din = nullptr, *dout = nullptr;
+  auto cleanup = [&]() {
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+  };
+#define W_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(FD_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  W_TRY(hipMalloc((void**)&din, (size_t)n * 4));
+  W_TRY(hipMalloc((void**)&dout, (size_t)n * 4));
+  W_TRY(hipMemcpy(din, in, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (which == 0) launch_wrap_test_f32(din, dout, n, nullptr);
+  else launch_wrap_test_img(din, dout, n, nullptr);
+  W_TRY(hipGetLastError());
+  W_TRY(hipDeviceSynchronize());
+  W_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+#undef W_TRY
   cleanup();
   return FD_OK;
 }

@@ -220,6 +220,24 @@ void launch_head_update_img(const UpdateArgs& a, const HeadImgArgs& ia, int max_
 void launch_ln_f32_img(const float* src, const float* gamma, const float* beta, float eps, const int* dims, void* out, int d,
                        float out_scale, int max_rows, hipStream_t s);
 
+// N2: the post-processing of sampling.sample (foldingdiff/sampling.py:200-222) on the device: per item the first lens[i]
+// positions of every stored state, shifted by the training mean offset and re-wrapped where the feature is an angle, packed into
+// one ragged buffer: item i's [rows][lens[i]][F] block starts at element item_off[i].
+struct ShiftTrimArgs {
+  const float* traj;           // [rows][B][L][F]
+  const int* lens;             // [B]
+  const long long* item_off;   // [B]
+  float* out;                  // ragged
+  int rows, B, L, F;
+  unsigned angle_mask;         // bit f: feature f is wrapped to [-pi, pi) after the shift
+  int has_offset;              // 0: neither shift nor wrap (the reference only wraps inside `if offset is not None`)
+  float offset[kMaxFeat];
+};
+void launch_shift_trim(const ShiftTrimArgs& a, hipStream_t s);
+// test hook: out[i] = wrap_pi(in[i]) through the update kernels' own device function (which: 0 rowwise.hip, 1 rowwise_img.hip)
+void launch_wrap_test_f32(const float* in, float* out, long long n, hipStream_t s);
+void launch_wrap_test_img(const float* in, float* out, long long n, hipStream_t s);
+
 void launch_build_rows(const int* lens, int B, int L, int packed, int cap, int* seq_row0, int* nrow, int2* rowinfo,
                        int* dims, hipStream_t s);
 // fp32 [src_rows][K] -> image [rows][K/32] (rows >= src_rows are zero rows), value * scale = hi + lo; and back

@@ -227,10 +227,12 @@ __global__ __launch_bounds__(256) void gemm_ln_rows_kernel(GemmImgArgs p) {
 template <int NKT>
 static void launch(const GemmImgArgs& p, int max_rows, hipStream_t s) {
   constexpr int SMEM = NKT * 4096 + 3 * BN * 4 + 2 * 32 * 4 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};  // (the attribute is per device)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_rows_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   // one workgroup per 32-row group of the workspace's capacity (groups beyond the actual row count compute padding rows, as the
   // tile kernel's last tile does)

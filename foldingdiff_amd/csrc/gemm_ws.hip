@@ -327,27 +327,33 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmImgArgs p) {
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 }
 
-static int n_cu() {
-  static int cached = 0;
-  if (!cached) {
-    int dev = 0;
+static int current_device() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? dev : 0;
+}
+static int n_cu() {  // per device (a process may hold models on several GPUs: fd_create takes any device_id)
+  static int cached[64] = {0};
+  const int dev = current_device();
+  if (!cached[dev]) {
     hipDeviceProp_t prop;
-    cached = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                 ? prop.multiProcessorCount : 256;
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  return cached;
+  return cached[dev];
 }
 
 template <int EPI>
 static void launch(const GemmImgArgs& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};  // (the attribute is per device)
+  const int dev = current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   static const bool want_stamps = [] { const char* e = getenv("FDMI_WS_STAMPS"); return e && atoi(e) != 0; }();
   static int dumped = 0;
-  if (want_stamps && dumped < 2 && p.N >= 512) {  // debug: the 4th launch of a wide shape is stamped and printed (stderr)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (want_stamps) (void)hipStreamIsCapturing(s, &cap);  // (its allocations and synchronisation would invalidate a capture in progress)
+  if (want_stamps && cap == hipStreamCaptureStatusNone && dumped < 2 && p.N >= 512) {  // debug: the 4th launch of a wide shape is stamped and printed (stderr)
     static int calls = 0;
     if (++calls == 4) {
       unsigned long long* d = nullptr;

@@ -317,6 +317,11 @@ __device__ __forceinline__ float wrap_pi(float v) {
   return __fadd_rn(m, -PI_F);
 }
 
+__global__ void wrap_test_f32_kernel(const float* in, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wrap_pi(in[i]);
+}
+
 template <int NJ>
 __global__ __launch_bounds__(256) void head_update_kernel(UpdateArgs a) {
   const int lane = threadIdx.x & 63;
@@ -465,5 +470,9 @@ void launch_head_update(const UpdateArgs& a, hipStream_t s) {
 
 __global__ void step_advance_kernel(int* t_dev) { *t_dev -= 1; }
 void launch_step_advance(int* t_dev, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, t_dev); }
+
+void launch_wrap_test_f32(const float* in, float* out, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(wrap_test_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
 
 }  // namespace fdmi

@@ -551,6 +551,37 @@ void launch_qkv_unpack(const void* src, float* dst, long long BH, int LTOT, int 
                      static_cast<const unsigned char*>(src), dst, BH, LTOT, LP, rowbytes, is_vt, 1.0f / scale);
 }
 
+// N2: one block per (item, stored state); the item's len * F values of that state are contiguous in both buffers.
+// Arithmetic of foldingdiff/sampling.py:218-222 on float32 arrays: s + offset (one rounded add), then for angular features
+// utils.modulo_with_wrapped_range(., -pi, pi) = wrap_pi -- the same bits as numpy's float32 operations.
+__global__ __launch_bounds__(256) void shift_trim_kernel(ShiftTrimArgs a) {
+  const int i = blockIdx.x / a.rows, j = blockIdx.x - i * a.rows;
+  const int n = a.lens[i] * a.F;
+  const float* src = a.traj + ((size_t)j * a.B + i) * a.L * a.F;
+  float* dst = a.out + a.item_off[i] + (size_t)j * n;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    float v = src[idx];
+    if (a.has_offset) {
+      const int f = idx % a.F;
+      v = __fadd_rn(v, a.offset[f]);
+      if ((a.angle_mask >> f) & 1u) v = wrap_pi(v);
+    }
+    dst[idx] = v;
+  }
+}
+void launch_shift_trim(const ShiftTrimArgs& a, hipStream_t s) {
+  if (a.B < 1 || a.rows < 1) return;
+  hipLaunchKernelGGL(shift_trim_kernel, dim3((unsigned)a.B * a.rows), dim3(256), 0, s, a);
+}
+
+__global__ void wrap_test_img_kernel(const float* in, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wrap_pi(in[i]);
+}
+void launch_wrap_test_img(const float* in, float* out, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(wrap_test_img_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
 void launch_img_to_f32(const void* src, float* dst, long long rows, int K, float scale, hipStream_t s) {
   hipLaunchKernelGGL(img_to_f32_kernel, dim3(blocks_for(rows * (K / 4))), dim3(256), 0, s,
                      static_cast<const unsigned char*>(src), dst, rows, K, 1.0f / scale);

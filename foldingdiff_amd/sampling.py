@@ -136,7 +136,7 @@ class _StepNoise:
 
 
 def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start: int, noise: _StepNoise, seq_offset: int,
-                            out: np.ndarray, full_history: int) -> None:
+                            out: Optional[np.ndarray], full_history: int, rows: Optional[int] = None) -> torch.Tensor:
     """Reverse steps t_start .. 0 with the step noise streamed to the device (fd_sample_begin_dev / _steps_dev /
     _end_dev): chunk k + 1 is drawn by a host thread and uploaded on a copy stream while the device runs chunk k."""
     import threading
@@ -156,7 +156,7 @@ def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start:
     consumed = [None, None]
     x_d = torch.from_numpy(x0).to(dev)
     lens_d = torch.from_numpy(lens).to(dev)
-    rows = out.shape[0]
+    rows = out.shape[0] if out is not None else rows
     out_d = torch.empty((rows, B, L, F), dtype=torch.float32, device=dev)
     torch.cuda.current_stream(dev).synchronize()
     chunks = list(noise.chunks(nrow))
@@ -207,7 +207,27 @@ def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start:
         th.join()
         run_s.synchronize()
         copy_s.synchronize()
-    out[:] = out_d.cpu().numpy()
+    if out is not None:
+        out[:] = out_d.cpu().numpy()
+    return out_d  # (``out`` None: the stored states stay on the device -- sample() post-processes them there)
+
+
+def _run_fd_sample_device(model, h, x0: np.ndarray, lens: np.ndarray, t_start: int, zs: Optional[np.ndarray], seed: int,
+                          seq_offset: int, rows: int, full_history: int) -> torch.Tensor:
+    """fd_sample_dev on device copies of a host batch; the [rows, B, L, F] result stays on the device."""
+    dev = model.device
+    B, L, F = x0.shape
+    x_d, lens_d = torch.from_numpy(x0).to(dev), torch.from_numpy(lens).to(dev)
+    z_d = torch.from_numpy(zs).to(dev) if zs is not None else None
+    out_d = torch.empty((rows, B, L, F), dtype=torch.float32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    lib = _binding.load()
+    _binding.check(lib.fd_sample_dev(h, C.c_void_p(x_d.data_ptr()), C.c_void_p(lens_d.data_ptr()), B, L, t_start,
+                                     C.c_void_p(z_d.data_ptr()) if z_d is not None else None, C.c_uint64(seed),
+                                     C.c_int64(seq_offset), C.c_void_p(out_d.data_ptr()), full_history, None))
+    _binding.check(lib.fd_synchronize(h))
+    _binding.check(lib.fd_check_finite(h))
+    return out_d
 
 
 _run_fd_sample_default = _run_fd_sample
@@ -229,6 +249,7 @@ def p_sample_loop(
     seed: Optional[int] = None,
     seq_offset: int = 0,
     draw_batch: Optional[Tuple[int, int, int]] = None,
+    _device_out: bool = False,
 ) -> torch.Tensor:
     """Run the whole reverse process from ``noise``.  Returns a CPU tensor of shape
     (timesteps, batch_size, seq_len, n_ft) -- entry j is the state after step
@@ -260,8 +281,15 @@ def p_sample_loop(
         assert hi - lo == B
         stream = _StepNoise(timesteps - 1, (b_all, L, F), (lo, hi))
         rows = 1 if final_only else -(-timesteps // history_every)
+        on_gpu = _run_fd_sample is _run_fd_sample_default and getattr(getattr(model, "device", None), "type", "") == "cuda"
+        if _device_out and on_gpu:  # (private: sample() keeps the stored states on the device for its post-processing)
+            if STREAM_NOISE:
+                return _run_fd_sample_streamed(model, h, x0, lens, timesteps - 1, stream, seq_offset, None,
+                                               0 if final_only else history_every, rows=rows)
+            return _run_fd_sample_device(model, h, x0, lens, timesteps - 1, stream.materialize(), 0, seq_offset, rows,
+                                         0 if final_only else history_every)
         out = np.empty((rows, B, L, F), dtype=np.float32)
-        if STREAM_NOISE and _run_fd_sample is _run_fd_sample_default and getattr(getattr(model, "device", None), "type", "") == "cuda":
+        if STREAM_NOISE and on_gpu:
             _run_fd_sample_streamed(model, h, x0, lens, timesteps - 1, stream, seq_offset, out, 0 if final_only else history_every)
         else:
             _run_fd_sample(h, x0, lens, timesteps - 1, stream.materialize(), 0, seq_offset, out, 0 if final_only else history_every)
@@ -271,6 +299,8 @@ def p_sample_loop(
     else:
         raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
     rows = 1 if final_only else -(-timesteps // history_every)
+    if _device_out and _run_fd_sample is _run_fd_sample_default and getattr(getattr(model, "device", None), "type", "") == "cuda":
+        return _run_fd_sample_device(model, h, x0, lens, timesteps - 1, zs, seed, seq_offset, rows, 0 if final_only else history_every)
     out = np.empty((rows, B, L, F), dtype=np.float32)
     _run_fd_sample(h, x0, lens, timesteps - 1, zs, seed, seq_offset, out, 0 if final_only else history_every)
     return torch.from_numpy(out)
@@ -379,6 +409,21 @@ def sample(
     logging.info(f"Sampling {len(lengths)} items in batches of size {batch_size}")
     world, rank = _dist_world()
     T = train_dset.timesteps
+    # the training mean offset (datasets.py get_masked_means; sampling.py:208-216), known before the first batch: every batch is
+    # cut to its items' lengths, shifted and re-wrapped ON THE DEVICE (fd_shift_trim_dev) and comes back as one ragged copy
+    inner = getattr(train_dset, "dset", None)
+    offset = None
+    if inner is not None and hasattr(inner, "get_masked_means"):
+        try:
+            offset = inner.get_masked_means()
+        except NotImplementedError:
+            # AnglesEmptyDataset without training_mean_offset.npy: the reference would
+            # raise here (datasets.py:613-617); treat "no offset" as "no shift".
+            offset = None
+    if offset is not None:
+        logging.info(f"Shifting predicted values by original offset: {offset}")
+    angular = np.asarray(train_dset.feature_is_angular[feature_key], dtype=bool)
+    on_gpu = _run_fd_sample is _run_fd_sample_default and getattr(getattr(model, "device", None), "type", "") == "cuda"
     results: List[np.ndarray] = []
     for start in range(0, len(lengths), batch_size):
         these = lengths[start : start + batch_size]
@@ -400,6 +445,7 @@ def sample(
         bounds = fdist.shard_by_tokens(these, world) if world > 1 else [(0, B)]
         lo, hi = bounds[rank]
         rows = 1 if final_only else -(-T // history_every)
+        home = model.device if on_gpu else torch.device("cpu")  # where a batch's stored states live until they are trimmed
         local_error = None
         if hi > lo:
             prev_varlen = model.set_option("varlen", 1)
@@ -408,42 +454,68 @@ def sample(
                     model=model, lengths=these[lo:hi], noise=noise[lo:hi], timesteps=T,
                     betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
                     disable_pbar=disable_pbar, final_only=final_only, history_every=history_every,
-                    seed=seed, seq_offset=lo, draw_batch=(B, lo, hi))
+                    seed=seed, seq_offset=lo, draw_batch=(B, lo, hi), _device_out=on_gpu)
             except Exception as e:  # e.g. FD_E_NONFINITE from this rank's slice: every rank must learn of it before the gather
                 if world == 1:
                     raise
                 local_error = e
-                traj = torch.zeros((rows, hi - lo, L, F), dtype=torch.float32)
+                traj = torch.zeros((rows, hi - lo, L, F), dtype=torch.float32, device=home)
             finally:
                 model.set_option("varlen", prev_varlen if prev_varlen is not None else 0)
         else:
             if NOISE_MODE == "torch":  # an empty shard still advances the generator exactly as the other ranks do
                 _StepNoise(T - 1, (B, L, F), (0, 0)).materialize()
-            traj = torch.zeros((rows, 0, L, F), dtype=torch.float32)
+            traj = torch.zeros((rows, 0, L, F), dtype=torch.float32, device=home)
         if world > 1:  # the single exchange of the path: [b_r, rows, L, F] blocks -> every rank holds the whole batch
             device = getattr(model, "device", torch.device("cpu"))
             failed = fdist.any_rank_failed(local_error is not None, device)   # one tiny all-reduce: all ranks abort together
             if failed:
                 raise RuntimeError(f"rank {rank}: sampling failed on " + ("this rank: " + repr(local_error) if local_error else "another rank"))
+            # (device-resident blocks stay on the device through the collective: RCCL reads and writes HBM directly)
             full = fdist.all_gather_batches(traj.permute(1, 0, 2, 3).contiguous(), [h_ - l_ for l_, h_ in bounds], device)
-            traj = full.permute(1, 0, 2, 3)
-        results.extend(traj[:, i, :l, :].numpy().copy() for i, l in enumerate(these))
-    inner = getattr(train_dset, "dset", None)
-    offset = None
-    if inner is not None and hasattr(inner, "get_masked_means"):
-        try:
-            offset = inner.get_masked_means()
-        except NotImplementedError:
-            # AnglesEmptyDataset without training_mean_offset.npy: the reference would
-            # raise here (datasets.py:613-617); treat "no offset" as "no shift".
-            offset = None
-    if offset is not None:
-        logging.info(f"Shifting predicted values by original offset: {offset}")
-        results = [s + offset for s in results]
-        angular_idx = np.where(train_dset.feature_is_angular[feature_key])[0]
-        for s in results:
-            s[..., angular_idx] = utils.modulo_with_wrapped_range(s[..., angular_idx], range_min=-np.pi, range_max=np.pi)
+            traj = full.permute(1, 0, 2, 3).contiguous()
+        results.extend(_shift_trim(model, traj, these, offset, angular))
     return results
+
+
+def _shift_trim(model, traj: torch.Tensor, lengths: Sequence[int], offset: Optional[np.ndarray], angular: np.ndarray) -> List[np.ndarray]:
+    """The tail of the reference's ``sample`` (foldingdiff/sampling.py:200-222) for one batch: item i = the first
+    ``lengths[i]`` positions of every stored state, plus the training mean offset, angular features re-wrapped to
+    [-pi, pi).  ``traj``: [rows, B, L, F].  A CUDA tensor is processed by ``fd_shift_trim_dev`` (one launch, one ragged
+    device-to-host copy; the arrays returned are views of that buffer); a float32 offset is applied there with the
+    reference's float32 arithmetic (bit-identical), any other offset dtype after the copy, vectorised over the whole buffer
+    in numpy's promoted dtype -- exactly what ``s + offset`` gives in the reference."""
+    rows, B, L, F = traj.shape
+    assert B == len(lengths)
+    sizes = np.array([rows * int(l) * F for l in lengths], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    off32 = offset is not None and np.asarray(offset).dtype == np.float32
+    if traj.is_cuda:
+        dev = traj.device
+        h = model._ensure_handle()
+        lens_d = torch.tensor([int(l) for l in lengths], dtype=torch.int32, device=dev)
+        item_off = torch.from_numpy(offs[:-1].copy()).to(dev)
+        out_d = torch.empty((int(offs[-1]),), dtype=torch.float32, device=dev)
+        o32 = np.ascontiguousarray(offset, dtype=np.float32) if off32 else None
+        torch.cuda.current_stream(dev).synchronize()
+        lib = _binding.load()
+        _binding.check(lib.fd_shift_trim_dev(h, C.c_void_p(traj.data_ptr()), rows, B, L, C.c_void_p(lens_d.data_ptr()),
+                                             C.c_void_p(item_off.data_ptr()), o32.ctypes.data_as(C.c_void_p) if o32 is not None else None,
+                                             C.c_void_p(out_d.data_ptr()), None))
+        _binding.check(lib.fd_synchronize(h))
+        flat = out_d.cpu().numpy()
+    else:  # host tensors (the CPU stand-in of the multi-process tests): the same ragged buffer, assembled with numpy
+        t = traj.numpy()
+        flat = np.concatenate([t[:, i, : int(l), :].reshape(-1) for i, l in enumerate(lengths)]) if B else np.zeros((0,), np.float32)
+        if off32:
+            flat = flat.reshape(-1, F) + np.asarray(offset)
+            flat[:, angular] = utils.modulo_with_wrapped_range(flat[:, angular], range_min=-np.pi, range_max=np.pi)
+            flat = flat.reshape(-1)
+    if offset is not None and not off32:  # e.g. a float64 offset file: numpy promotes, as in the reference
+        flat = flat.reshape(-1, F) + np.asarray(offset)
+        flat[:, angular] = utils.modulo_with_wrapped_range(flat[:, angular], range_min=-np.pi, range_max=np.pi)
+        flat = flat.reshape(-1)
+    return [flat[offs[i]: offs[i + 1]].reshape(rows, int(l), F) for i, l in enumerate(lengths)]
 
 
 @torch.no_grad()

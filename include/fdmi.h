@@ -237,6 +237,19 @@ int fd_nerf(int device_id, const float* feats, const int32_t* lens, int B, int L
 int fd_test_gemm(int device_id, int precision, int epilogue, const float* A, const float* W, const float* bias,
                  const float* resid, float* C, int M, int N, int K);
 
+/* N2: the post-processing of sampling.sample -- foldingdiff/sampling.py:200-222: cut every item to its length, add the
+ * training mean offset (datasets.py get_masked_means), re-wrap the angular features with utils.modulo_with_wrapped_range(., -pi, pi)
+ * -- on the device, bit-identical to the reference's float32 numpy arithmetic.  traj_dev: [rows][B][L][F] float32 (the stored states
+ * of fd_sample_dev, F = fd_config.n_features); lens_dev: int32 [B]; item_off_dev: int64 [B], element offset of item i's
+ * [rows][lens[i]][F] block inside out_dev; offset: HOST float32 [F], or NULL = neither shift nor wrap (what the reference does
+ * without an offset).  Angularity is what fd_finalize was given.  Asynchronous on hip_stream (NULL: the model's own stream). */
+int fd_shift_trim_dev(fd_model* m, const void* traj_dev, int rows, int B, int L, const void* lens_dev, const void* item_off_dev,
+                      const float* offset, void* out_dev, void* hip_stream);
+
+/* Test hook for utils.modulo_with_wrapped_range (foldingdiff/utils.py:87-121): out[i] = the update kernels' own wrap of in[i]
+ * (host arrays of n float32).  which: 0 = the FD_PREC_F32 kernels' copy (rowwise.hip), 1 = the default path's (rowwise_img.hip). */
+int fd_test_wrap(int device_id, int which, const float* in, int64_t n, float* out);
+
 /* C = LayerNorm(A W^T + bias + resid) * gamma + beta over full rows (HF BertSelfOutput / BertOutput,
  * reached from modelling.py:473-480).  use_fused != 0 asks for the LN-fused GEMM kernel of that precision
  * (FD_E_UNSUPPORTED if the shape has no fused instantiation); 0 runs GEMM(+residual) then the LayerNorm kernel. */

@@ -190,3 +190,30 @@ def test_a_failure_on_one_rank_aborts_every_rank():
         assert p.exitcode == 0
     assert "this rank" in got[1] and "non-finite" in got[1]
     assert "another rank" in got[0]
+
+
+@pytest.mark.gpu
+def test_two_gpu_rccl_sample_and_c_abi_gather():
+    """The N > 1 path on REAL devices: two processes, one per GPU, backend nccl = RCCL over xGMI.  Skipped on a
+    one-GPU box; the first multi-GPU lease runs sampling.sample's all-gather, fd_comm_init / fd_gather_dev and (below) bench.py
+    --gpus 2 without any new code."""
+    import subprocess
+    import sys
+    from foldingdiff_amd import _binding
+    if _binding.load().fd_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(repo, "tests", "_rccl_worker.py")]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("RCCL sample + fd_gather_dev OK") == 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--timesteps", "20", "--batch", "64"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dist"]["backend"] == "nccl" and line["config"]["global_batch"] == 128

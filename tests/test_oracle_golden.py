@@ -171,3 +171,106 @@ def test_nerf_oracle_vs_reference_golden():
                                      col.get("C:1N:1CA"), center=center, len_c_n=col.get("0C:1N"),
                                      len_n_ca=col.get("N:CA"), len_ca_c=col.get("CA:C"))
                 assert np.array_equal(got, g[f"{tag}_{Ln}_{key}"]), (tag, Ln, key)
+
+
+# ------------------------------------------------------------ relative_key / relative_key_query
+# HF transformers 4.11.3's BertSelfAttention (requirements.txt:6 of the reference; constructed at foldingdiff/modelling.py:271) is
+# not installable here and transformers 5.x dropped the feature from BERT: PARITY WITH 4.11.3 ITSELF STAYS UNPINNED until that
+# version or a released checkpoint is available.  What can be checked, and is checked on every run: (1) the one HuggingFace
+# module that still implements the same einsum, (2) a structurally different index-by-index restatement of the published algorithm.
+def _oracle_attention(pos, H, dh, maxpos, seed):
+    cfg = ref_model.OracleConfig(hidden_size=H * dh, num_attention_heads=H, intermediate_size=64, num_hidden_layers=1,
+                                 max_position_embeddings=maxpos, position_embedding_type=pos)
+    att = ref_model.BertSelfAttention(cfg).eval()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for lin in (att.query, att.key, att.value):
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.2)
+            lin.bias.copy_(torch.randn(lin.bias.shape, generator=g) * 0.1)
+        att.distance_embedding.weight.copy_(torch.randn(att.distance_embedding.weight.shape, generator=g) * 0.3)
+    return att, g
+
+
+@pytest.mark.parametrize("L", [50, 101, 128])
+def test_relative_key_matches_huggingface_wav2vec2_bert(L):
+    """The released geometry (maxpos 128, head size 32) against Wav2Vec2BertSelfAttention: the same
+    einsum("bhld,lrd->bhlr", q, E[dist]) added to the scores, with dist = r - l (BERT 4.11.3: l - r), i.e. the flipped table.
+    Compared on the context BEFORE the output projection (linear_out = identity)."""
+    tf = pytest.importorskip("transformers")
+    try:
+        from transformers.models.wav2vec2_bert.configuration_wav2vec2_bert import Wav2Vec2BertConfig
+        from transformers.models.wav2vec2_bert.modeling_wav2vec2_bert import Wav2Vec2BertSelfAttention
+    except Exception as e:  # an older / newer transformers without the model
+        pytest.skip(f"transformers {tf.__version__} has no Wav2Vec2Bert: {e}")
+    maxpos, H, dh, B = 128, 4, 32, 3
+    att, g = _oracle_attention("relative_key", H, dh, maxpos, seed=L)
+    wc = Wav2Vec2BertConfig(hidden_size=H * dh, num_attention_heads=H, position_embeddings_type="relative_key",
+                            left_max_position_embeddings=maxpos - 1, right_max_position_embeddings=maxpos - 1, attention_dropout=0.0)
+    w = Wav2Vec2BertSelfAttention(wc).eval()
+    with torch.no_grad():
+        for a, b in ((w.linear_q, att.query), (w.linear_k, att.key), (w.linear_v, att.value)):
+            a.weight.copy_(b.weight)
+            a.bias.copy_(b.bias)
+        w.linear_out.weight.copy_(torch.eye(H * dh))
+        w.linear_out.bias.zero_()
+        w.distance_embedding.weight.copy_(torch.flip(att.distance_embedding.weight, dims=(0,)))
+        hs = torch.randn(B, L, H * dh, generator=g)
+        lens = [L, max(1, (2 * L) // 3), 1]  # ragged: a full sequence, a partly masked one, a single key
+        ext = torch.zeros(B, 1, 1, L)
+        for i, n in enumerate(lens):
+            ext[i, ..., n:] = -10000.0  # (1 - mask) * -10000, modelling.py:450-452
+        want = w(hs, attention_mask=ext)[0]
+        got = att(hs, ext)
+    for i, n in enumerate(lens):  # rows of masked QUERIES are computed by both but mean nothing
+        assert (got[i, :n] - want[i, :n]).abs().max().item() <= 1e-5, (L, i)
+
+
+def _loops_attention(q, k, v, E, maxpos, lens, pos):
+    """SURVEY 8c's pseudocode element by element in float64 (no einsum, no broadcasting): q, k, v [B, H, L, dh], E [2 maxpos - 1, dh]."""
+    B, H, L, dh = q.shape
+    out = np.zeros((B, L, H * dh))
+    for b in range(B):
+        for h in range(H):
+            for l in range(L):
+                s = np.empty(L)
+                for r in range(L):
+                    e = E[l - r + maxpos - 1]                      # distance l - r, shifted into the table
+                    acc = float(np.dot(q[b, h, l], k[b, h, r]))    # q . k
+                    acc += float(np.dot(q[b, h, l], e))            # relative_key: q_l . E[l - r]
+                    if pos == "relative_key_query":
+                        acc += float(np.dot(k[b, h, r], e))        # ... and k_r . E[l - r]
+                    acc /= np.sqrt(dh)                             # scale AFTER the relative terms
+                    if r >= lens[b]:
+                        acc += -10000.0                            # additive mask, after the scale
+                    s[r] = acc
+                p = np.exp(s - s.max())
+                p /= p.sum()
+                for d in range(dh):
+                    out[b, l, h * dh + d] = float(np.dot(p, v[b, h, :, d]))
+    return out
+
+
+@pytest.mark.parametrize("pos", ["relative_key", "relative_key_query"])
+def test_relative_position_scores_vs_index_loops(pos):
+    """A second restatement of HF 4.11.3 BertSelfAttention.forward, written as scalar loops from SURVEY 8c's pseudocode, against the
+    oracle's vectorised module -- the only independent check the relative_key_query key term has."""
+    maxpos, H, dh, B, L = 24, 2, 8, 2, 19
+    att, g = _oracle_attention(pos, H, dh, maxpos, seed=7)
+    att = att.double()
+    hs = torch.randn(B, L, H * dh, generator=g).double()
+    lens = [L, 11]
+    ext = torch.zeros(B, 1, 1, L, dtype=torch.float64)
+    for i, n in enumerate(lens):
+        ext[i, ..., n:] = -10000.0
+    with torch.no_grad():
+        got = att(hs, ext).numpy()
+        split = lambda x: x.view(B, L, H, dh).permute(0, 2, 1, 3).numpy()
+        q, k, v = split(att.query(hs)), split(att.key(hs)), split(att.value(hs))
+    want = _loops_attention(q, k, v, att.distance_embedding.weight.detach().numpy(), maxpos, lens, pos)
+    for i, n in enumerate(lens):
+        assert np.abs(got[i, :n] - want[i, :n]).max() <= 1e-12, (pos, i)
+    if pos == "relative_key_query":  # the key term is not a no-op of the test
+        rk, _ = _oracle_attention("relative_key", H, dh, maxpos, seed=7)
+        rk = rk.double()
+        with torch.no_grad():
+            assert (rk(hs, ext) - torch.from_numpy(got)).abs().max().item() > 1e-3
