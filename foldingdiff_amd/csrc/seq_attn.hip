@@ -89,6 +89,31 @@ __device__ __forceinline__ int sload(const int* base, int index) {
   return v;
 }
 
+#ifndef FDMI_SA_ASM_MFMA
+#define FDMI_SA_ASM_MFMA 1  // 1: the attention's MFMAs are written in assembly with their accumulators in VGPRs
+#endif
+// The attention's accumulators (S^T, the band tiles, O^T) are VALU / LDS operands right after their last MFMA.  hipcc gives the
+// builtin's result the AGPR half of the register file and copies it out (16 v_accvgpr_read per tile, ~160 per head, in a kernel
+// that is bound by its instruction count); written in assembly the accumulator IS a VGPR tuple.  The compiler cannot see that these
+// statements are matrix instructions, so the hazards are this file's business: their A / B operands come from LDS reads (the
+// compiler still waits for those) or were written by VALU instructions several MFMAs earlier; their results are read by other
+// instructions no sooner than two projection MFMAs (64 cycles) later; chained MFMAs name exactly the same accumulator tuple.
+__device__ __forceinline__ void mfma_acc(f32x16& d, const f16x8& a, const f16x8& b) {  // d += a b
+#if FDMI_SA_ASM_MFMA
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+#else
+  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, d, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void mfma_new(f32x16& d, const f16x8& a, const f16x8& b) {  // d = a b
+#if FDMI_SA_ASM_MFMA
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+#else
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, z, 0, 0, 0);
+#endif
+}
+
 constexpr int T = 4, LP = 128;          // key tiles of 32, keys per sequence tile
 constexpr int NST = 4;                  // weight ring stages
 constexpr int KT_BYTES = 96 * 128;      // one k-tile of a head's 96 weight rows
@@ -417,10 +442,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     constexpr int t = decltype(TT)::value, i = decltype(I)::value, c = i / 3, j = i % 3;
     const f16x8 a = __builtin_bit_cast(f16x8, kf[j == 2 ? 2 + c : c]);
     const f16x8& b = j == 1 ? ql[c] : qh[c];
-    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, i == 0 ? zero16 : sacc[t], 0, 0, 0);
-    // (the scores are VALU operands from here on: as an accumulator in the AGPR half of the register file every later use costs a
-    // v_accvgpr_read, and this kernel is bound by its instruction count)
-    if constexpr (i == 5) asm volatile("" : "+v"(sacc[t]));
+    if constexpr (i == 0) mfma_new(sacc[t], a, b);
+    else mfma_acc(sacc[t], a, b);
+    if constexpr (i == 5 && !FDMI_SA_ASM_MFMA) asm volatile("" : "+v"(sacc[t]));
   };
   auto e_reads = [&](auto QQ, u32x4 (&e)[4]) __attribute__((always_inline)) {  // e[0] hi c0, e[1] hi c1, e[2] lo c0, e[3] lo c1 of the lane's band row
     constexpr int qq = decltype(QQ)::value;
@@ -439,8 +463,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     constexpr int qq = decltype(QQ)::value, i = decltype(I)::value, c = i / 3, j = i % 3;
     const f16x8 a = __builtin_bit_cast(f16x8, e[j == 1 ? 2 + c : c]);
     const f16x8& b = j == 2 ? ql[c] : qh[c];
-    racc[qq & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, i == 0 ? zero16 : racc[qq & 1], 0, 0, 0);
-    if constexpr (i == 5) asm volatile("" : "+v"(racc[qq & 1]));  // (ds_write_addtid takes VGPRs: see s_mm1)
+    if constexpr (i == 0) mfma_new(racc[qq & 1], a, b);
+    else mfma_acc(racc[qq & 1], a, b);
+    if constexpr (i == 5 && !FDMI_SA_ASM_MFMA) asm volatile("" : "+v"(racc[qq & 1]));
   };
   auto op_W = [&](auto QQ) __attribute__((always_inline)) {  // scratch slot qq & 1 <- racc[qq & 1]: register r of all 64 lanes lands as band rows 2 r, 2 r + 1
     constexpr int qq = decltype(QQ)::value;
@@ -525,8 +550,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     constexpr int g = decltype(G)::value, j = decltype(J)::value, bf = g & 1;
     const f16x8& a = j == 1 ? pvl[bf] : pvh[bf];
     const f16x8& b = j == 2 ? ppl[bf] : pph[bf];
-    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, (g == 0 && j == 0) ? zero16 : oacc, 0, 0, 0);
-    if constexpr (g == 7 && j == 2) asm volatile("" : "+v"(oacc));
+    if constexpr (g == 0 && j == 0) mfma_new(oacc, a, b);
+    else mfma_acc(oacc, a, b);
+    if constexpr (g == 7 && j == 2 && !FDMI_SA_ASM_MFMA) asm volatile("" : "+v"(oacc));
   };
 
   // slot k (0..17; -1: in front of the stage's first projection MFMA) of attention slice s.  `ph`: the head whose projection
