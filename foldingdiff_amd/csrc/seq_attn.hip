@@ -36,6 +36,10 @@
 #define FDMI_SA_SCHED 0  // 0: the source order of the slots is the schedule (sched_barrier between them); 1: the slots' order only holds for
                          // the MFMAs, everything else of a stage is dealt out evenly behind them with sched_group_barrier
 #endif
+#ifndef FDMI_SA_SKIP
+#define FDMI_SA_SKIP 0  // ablation builds (wrong results, and a skipped epilogue lets hipcc drop the projection it feeds): bit s = the
+                        // attention slice of stage s is left out
+#endif
 #ifndef FDMI_SA_DBG
 #define FDMI_SA_DBG 0  // ablation builds (wrong results): 1 = no attention slices, 2 = no projection MFMAs, 4 = no ctx stores
 #endif
@@ -560,6 +564,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   auto attn_slot = [&](auto S, auto K, int ph) __attribute__((always_inline)) {
     constexpr int s = decltype(S)::value, k = decltype(K)::value;
     if (FDMI_SA_DBG & 1) return;
+    if constexpr (((FDMI_SA_SKIP >> s) & 1) != 0) return;
     if constexpr (s == 0) {
       // (q and k here: the S^T tiles of the next stage want them; v and the ctx block of the head before ride in the two S^T
       // stages, which are light on VALU work)

@@ -23,10 +23,16 @@ if os.environ.get("SPLIT_QKV"):
 lib = _binding.load()
 x = torch.randn(B, L, 6, device="cuda:0")
 lens = torch.full((B,), L, dtype=torch.int32, device="cuda:0")
-sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=1)
+try:
+    sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=1)
+except _binding.FdmiError as e:
+    print("ignored:", e, file=sys.stderr)
 _binding.check(lib.fd_profile_reset(h))
 _binding.check(lib.fd_profile_every(h, 1))
-sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=steps - 1)
+try:
+    sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=steps - 1)
+except _binding.FdmiError as e:  # (ablation builds produce garbage, possibly non-finite: the times still stand)
+    print("ignored:", e, file=sys.stderr)
 _binding.check(lib.fd_profile_every(h, 0))
 name_p, ms, n, fl, by = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double(), C.c_double()
 tot = 0.0
