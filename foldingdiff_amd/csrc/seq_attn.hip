@@ -723,19 +723,17 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
       constexpr int kt = decltype(KT)::value;
       FD_STAMP(kt);
-      // the NEXT stage landed (this one did a stage ago): loads retire in order, so it is complete once no more loads are
-      // outstanding than were issued behind it (stores in flight only make the wait conservative).  Behind stage s+1: the 3 pieces
-      // of s+2, and -- while the hidden state is being re-loaded -- the 4 loads issued at the end of stages s-2 and s-1
+      // the NEXT stage landed (this one did a stage ago).  vmcnt retires in issue order (loads and stores alike: the compiler's own
+      // waits rest on that), so the stage is complete once no more operations are outstanding than were issued behind it: the 3
+      // pieces of the stage after it, the 4 ctx stores of stage 2 (seen from the tops of stages 3 and 4), and -- while the hidden
+      // state is being re-loaded -- the 4 loads issued at the end of the two stages before this one
+      constexpr int ST = (SPS == 1 && (kt == 3 || kt == 4)) ? 4 : 0;  // (d_model 192: the stores leave in stage 1; the plain count only waits longer)
       if (reload) {
-        if constexpr (kt == 0) FD_WAIT_VM(3);
-        else if constexpr (kt == 1) FD_WAIT_VM(7);
-        else FD_WAIT_VM(11);
+        FD_WAIT_VM(3 + ST + (kt == 0 ? 0 : (kt == 1 ? 4 : 8)));
       } else if (after_reload) {
-        if constexpr (kt == 0) FD_WAIT_VM(11);
-        else if constexpr (kt == 1) FD_WAIT_VM(7);
-        else FD_WAIT_VM(3);
+        FD_WAIT_VM(3 + ST + (kt == 0 ? 8 : (kt == 1 ? 4 : 0)));
       } else {
-        FD_WAIT_VM(3);
+        FD_WAIT_VM(3 + ST);
       }
       barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
       issue_w();
