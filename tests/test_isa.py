@@ -208,3 +208,48 @@ def test_the_few_rows_layernorm_gemm_is_spill_free(tmp_path):
     for name, body in metas:
         md = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", body)}
         assert md["vgpr_count"] <= 512 and md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
+
+
+# ------------------------------------------------------------ seq_attn.hip (round 5)
+@pytest.fixture(scope="module")
+def seq_attn_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "seq_attn.s"
+    try:
+        fbuild.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    cmd = [fbuild.find_hipcc(), "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include"),
+           "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, "seq_attn.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+def test_fused_attention_kernel_has_no_scratch_and_never_drains_the_weight_stream(seq_attn_asm):
+    """The production instantiations of sa::seq_attn_kernel (d_model 384 and 192): one wave per SIMD holds the hidden state in
+    registers, so a spill is a vector-memory load in the middle of the counted LDS-DMA stream (its vmcnt(0) drains the ring: the
+    first versions lost 5-12 k cycles per head to sixteen spilled address registers, profiles/r05_seq_attn_notes.log).  Pinned:
+    no scratch at all, no s_waitcnt vmcnt(0) between the loop header and the loop's end, 294 MFMAs per (sequence, head)
+    -- 216 projection + 78 attention -- in the d_model-384 loop, none of the attention's accumulators copied out of AGPRs."""
+    asm = seq_attn_asm
+    found = 0
+    for m in re.finditer(r"^(_ZN4fdmi2sa15seq_attn_kernelILi(\d+)ELb0EEEvNS_11SeqAttnArgsE):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
+        nkt, body = int(m.group(2)), m.group(3)
+        found += 1
+        assert "scratch_" not in body, nkt
+        lines = body.splitlines()
+        # the item loop = the LAST loop of the kernel (the first one uploads the bias to LDS)
+        hdr = max(i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l)
+        label = re.match(r"(\.LBB\d+_\d+):", lines[hdr]).group(1)
+        end = max(i for i, l in enumerate(lines) if re.search(r"s_c?branch\w* " + re.escape(label) + r"\b", l))
+        loop = lines[hdr:end + 1]
+        assert not any(re.search(r"s_waitcnt\s+vmcnt\(0\)", l) for l in loop), nkt
+        n_mfma = sum("v_mfma_f32_32x32x16_f16" in l for l in loop)
+        assert n_mfma == (18 * nkt + 78), (nkt, n_mfma)
+        # 48 = the projected head's three accumulators; the rest are loop-invariant values hipcc parks in AGPRs (20 and 42 today)
+        assert sum("v_accvgpr_read" in l for l in loop) <= 96, nkt
+        assert not any("v_accvgpr_write" in l for l in loop), nkt
+    assert found == 2
+    for m in re.finditer(r"\.name:\s+_ZN4fdmi2sa15seq_attn_kernelILi(\d+)ELb0EEEvNS_11SeqAttnArgsE\n(.*?)\.wavefront_size", asm, re.S):
+        fields = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(2))}
+        assert fields["private_segment_fixed_size"] == 0 and fields["vgpr_spill_count"] == 0, fields
