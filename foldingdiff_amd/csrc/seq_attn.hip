@@ -40,6 +40,10 @@
 #define FDMI_SA_SKIP 0  // ablation builds (wrong results, and a skipped epilogue lets hipcc drop the projection it feeds): bit s = the
                         // attention slice of stage s is left out
 #endif
+#ifndef FDMI_SA_EDGES
+#define FDMI_SA_EDGES 1  // 1: the first item's projection and the last item's attention run alone (their own code); 0: one loop body
+                         // for everything -- iteration 0 runs an attention on garbage, the last one a projection for nothing
+#endif
 #ifndef FDMI_SA_DBG
 #define FDMI_SA_DBG 0  // ablation builds (wrong results): 1 = no attention slices, 2 = no projection MFMAs, 4 = no ctx stores
 #endif
@@ -623,17 +627,22 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       if constexpr (k == 6) {
         dump16(112, sacc[0]); dump16(128, sacc[1]); dump16(144, sacc[2]); dump16(160, sacc[3]);  // S^T with the band
         // key mask: this lane + its partner (lane ^ 32) hold one query's scores
+        // (len <= Lb: a key tile that ends at or below len has nothing to mask; len is wave-uniform, and this slot is a block of
+        // its own anyway -- sequences of 97..128 positions touch the last tile only)
         if (len < LP) {
+          static_for<0, T>([&](auto TT) __attribute__((always_inline)) {
+            constexpr int t = decltype(TT)::value;
+            if (len < 32 * (t + 1)) {
 #pragma unroll
-          for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-              float sc = sacc[t][r];
-              if (key >= len) sc += mask_raw;  // (1 - mask) * -10000   (modelling.py:452)
-              if (key >= Lb) sc = -INFINITY;   // not a key at all (rows that do not exist)
-              sacc[t][r] = sc;
+              for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float sc = sacc[t][r];
+                if (key >= len) sc += mask_raw;  // (1 - mask) * -10000   (modelling.py:452)
+                if (key >= Lb) sc = -INFINITY;   // not a key at all (rows that do not exist)
+                sacc[t][r] = sc;
+              }
             }
+          });
         }
         mt = -INFINITY;
       }
@@ -680,7 +689,13 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       constexpr int a = 2 * kt, b = 2 * kt + 1;
       if constexpr (slot == -1) attn_slot(IC<a>{}, IC<-1>{}, ph);
       if constexpr (slot >= 0 && slot <= 8) { attn_slot(IC<a>{}, IC<2 * slot>{}, ph); attn_slot(IC<a>{}, IC<2 * slot + 1>{}, ph); }
-      if constexpr (slot == 8) attn_slot(IC<b>{}, IC<-1>{}, ph);
+      if constexpr (slot == 8) {
+        // slices 0 and 1 share stage 0: the K tiles that every wave wrote in slice 0 are read by every wave in slice 1 (with the
+        // projection's MFMAs pacing the slots the waves happened to stay ~2 slots apart; the attention-only last iteration showed
+        // the race)
+        if constexpr (kt == 0) barrier_keep_vm();
+        attn_slot(IC<b>{}, IC<-1>{}, ph);
+      }
       if constexpr (slot >= 9) { attn_slot(IC<b>{}, IC<2 * (slot - 9)>{}, ph); attn_slot(IC<b>{}, IC<2 * (slot - 9) + 1>{}, ph); }
     }
   };
@@ -713,8 +728,30 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   int head = 0;       // head of the item being projected
   int prev_head = 0;  // ... of the item before it, whose attention this iteration runs
   int prev_seq = seq, prev_row0 = p_row0;
-  for (int it = 0; it <= nitems; ++it) {
-    const bool real = it < nitems;
+#if FDMI_SA_EDGES
+  // ---- iteration 0: the projection of the first item alone (no attention slots: 12 stages of ~870 ticks instead of ~1660)
+  static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value;
+    FD_STAMP(kt);
+    FD_WAIT_VM(3);
+    barrier_keep_vm();
+    issue_w();
+    FD_SB();
+    static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
+      proj_mfma(KT, K);
+      FD_SB();
+    });
+    ++pos;
+  });
+  ++slot;
+  head = 1;
+  constexpr int IT0 = 1;
+#else
+  constexpr int IT0 = 0;
+#endif
+  const int it_end = FDMI_SA_EDGES ? nitems : nitems + 1;
+  for (int it = IT0; it < it_end; ++it) {
+    const bool real = FDMI_SA_EDGES ? true : it < nitems;
     // vector-memory bookkeeping of the stage-top waits: 0 plain (the 6 pieces of the two younger stages); 1 this iteration
     // re-loads the hidden state (4 more loads per stage); 2 the iteration after such a one
     const bool reload = real && head == H - 1 && seq + (int)gridDim.x < p.B;
@@ -736,6 +773,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
         FD_WAIT_VM(3 + ST);
       }
       barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
+      if constexpr (kt == 0) FD_STAMP(15);  // (instrumented build: stage 0 in pieces -- barrier | copy-out, slot -1 | slots 0-6 | 7-12 | 13-17)
       issue_w();
       if constexpr (kt == 0) {  // the finished head's accumulators leave the matrix registers: its epilogue runs under this stage
 #pragma unroll
@@ -747,11 +785,14 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       FD_SB();
       attn_at(KT, IC<-1>{}, prev_head);
       FD_SB();
+      if constexpr (kt == 0) FD_STAMP(12);
       static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
         proj_mfma(KT, K);
         if constexpr (FDMI_SA_SCHED == 0) FD_SB();
         attn_at(KT, K, prev_head);
         if constexpr (FDMI_SA_SCHED == 0) FD_SB();
+        if constexpr (kt == 0 && decltype(K)::value == 6) FD_STAMP(13);
+        if constexpr (kt == 0 && decltype(K)::value == 12) FD_STAMP(14);
       });
       if constexpr (FDMI_SA_SCHED != 0) {
         // behind every MFMA (their source order stands): a few VALU, one transcendental, two scalar, one LDS read, one LDS write
@@ -797,6 +838,42 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       }
     }
   }
+#if FDMI_SA_EDGES
+  // ---- the attention of the last item alone: no projection, no weight stream (what the stream requested beyond its end lands in
+  // free ring slots and is never read), the same barriers (K / V of the item travel between the waves through LDS)
+  static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value;
+    FD_STAMP(kt);
+    barrier_keep_vm();
+    if constexpr (kt == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) eo[j] = acc[j];
+    }
+    FD_SB();
+    attn_at(KT, IC<-1>{}, prev_head);
+    FD_SB();
+    static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
+      attn_at(KT, K, prev_head);
+      FD_SB();
+    });
+    if constexpr (kt == 0) {
+      a_head = prev_head;
+      if (prev_head == 0) {
+        row0 = prev_row0;
+        nrows = sload(p.seq_row0, prev_seq + 1) - row0;
+        Lb = sload(p.nrow, prev_seq);
+        len = sload(p.lens, prev_seq);
+      }
+    }
+    if constexpr (kt == (SPS == 1 ? 2 : 1)) {
+      c_head = a_head;
+      c_row0 = row0;
+      c_nrows = nrows;
+    }
+    FD_SB();
+  });
+  ++slot;
+#endif
   // the last item's ctx block
   c_head = a_head;
   c_row0 = row0;

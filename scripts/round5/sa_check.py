@@ -20,6 +20,7 @@ CASES = [
     dict(hidden=384, heads=12, ff=768, layers=2, B=3, L=97, lens=[97, 97, 33]),
     dict(hidden=192, heads=6, ff=384, layers=6, B=4, L=128, lens=[128, 50, 33, 100]),
     dict(hidden=384, heads=12, ff=768, layers=2, B=300, L=128, lens=None),
+    dict(hidden=384, heads=12, ff=768, layers=1, B=600, L=128, lens=None),
 ]
 bad = 0
 for cf in CASES:

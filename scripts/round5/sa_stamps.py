@@ -44,3 +44,6 @@ for w in (0, 3):
         last = int(nxt - r[11]) if nxt and r[11] else 0
         tot = int(nxt - r[0]) if nxt else 0
         print(f"  it {i:2d}: " + " ".join(f"{v:5d}" for v in d) + f" {last:6d} | {tot:7d}")
+        if r[12] and r[13] and r[14] and r[15]:  # stage 0 in pieces (main-loop iterations only)
+            pcs = [r[15] - r[0], r[12] - r[15], r[13] - r[12], r[14] - r[13], r[1] - r[14]]
+            print("         stage 0: wait+barrier %d | issue, copy-out, slot -1 %d | slots 0-6 %d | slots 7-12 %d | slots 13-17 %d" % tuple(int(v) for v in pcs))
