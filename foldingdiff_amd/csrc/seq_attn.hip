@@ -97,6 +97,15 @@ __device__ __forceinline__ int sload(const int* base, int index) {
   return v;
 }
 
+// three of them in flight together (a sequence's row range, row count and length: one after the other they cost ~1100 ticks each
+// on their first, cold, use: profiles/r05_seq_attn_notes.log)
+__device__ __forceinline__ void sload3(const int* a, int ia, const int* b, int ib, const int* c, int ic, int& x, int& y, int& z) {
+  asm volatile("s_load_dword %0, %3, %4\n\ts_load_dword %1, %5, %6\n\ts_load_dword %2, %7, %8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(x), "=&s"(y), "=&s"(z)
+               : "s"(a), "s"(ia * 4), "s"(b), "s"(ib * 4), "s"(c), "s"(ic * 4)
+               : "memory");
+}
+
 #ifndef FDMI_SA_ASM_MFMA
 #define FDMI_SA_ASM_MFMA 1  // 1: the attention's MFMAs are written in assembly with their accumulators in VGPRs
 #endif
@@ -812,9 +821,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
         a_head = prev_head;
         if (prev_head == 0 && it > 0) {
           row0 = prev_row0;
-          nrows = sload(p.seq_row0, prev_seq + 1) - row0;
-          Lb = sload(p.nrow, prev_seq);
-          len = sload(p.lens, prev_seq);
+          int r1;
+          sload3(p.seq_row0, prev_seq + 1, p.nrow, prev_seq, p.lens, prev_seq, r1, Lb, len);
+          nrows = r1 - row0;
         }
       }
       if constexpr (kt == (SPS == 1 ? 2 : 1)) {  // the ctx block of the head before has left: the next one belongs to the attention in flight
@@ -860,9 +869,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       a_head = prev_head;
       if (prev_head == 0) {
         row0 = prev_row0;
-        nrows = sload(p.seq_row0, prev_seq + 1) - row0;
-        Lb = sload(p.nrow, prev_seq);
-        len = sload(p.lens, prev_seq);
+        int r1;
+        sload3(p.seq_row0, prev_seq + 1, p.nrow, prev_seq, p.lens, prev_seq, r1, Lb, len);
+        nrows = r1 - row0;
       }
     }
     if constexpr (kt == (SPS == 1 ? 2 : 1)) {
