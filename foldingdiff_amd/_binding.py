@@ -17,7 +17,7 @@ FD_DEC = {"mlp": 0, "linear": 1}
 FD_PREC_F32 = 0
 FD_PREC_F16X3 = 1
 FD_PREC = {"f32": 0, "f16x3": 1}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FdmiError(RuntimeError):

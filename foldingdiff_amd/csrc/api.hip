@@ -897,9 +897,14 @@ int check_lens(const int32_t* lens, int B, int L) {
   return FD_OK;
 }
 
+// the workspace's captured graph still holds the launch sequence the model's options ask for
+static bool graph_current(const fd_model* m, const Workspace& w) {
+  return w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn;
+}
+
 int ensure_graph(fd_model* m) {
   Workspace& w = m->ws;
-  if (w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
+  if (graph_current(m, w)) return FD_OK;  // (a precision change goes through fd_finalize, which drops the workspace)
   if (w.graph) {
     (void)hipGraphExecDestroy(w.graph);
     w.graph = nullptr;
@@ -1468,7 +1473,7 @@ int fd_sample_begin_dev(fd_model* m, const void* x_init_dev, const void* lens_de
   if (m->varlen && full_history)  // packed rows: positions beyond a sequence's length are never written
     HIP_TRY(hipMemsetAsync(out_dev, 0, ((size_t)(t_start + full_history) / full_history) * n * 4, s));
   if (int rc = prepare_rows(m, s, m->varlen)) return rc;
-  if (m->use_graph && !(w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen)) {
+  if (m->use_graph && !graph_current(m, w)) {
     // first use of this (B, L): the warm-up step and the capture run on the model's stream and need the
     // lengths / row table that were just queued on `s`
     if (s != m->stream) HIP_TRY(hipStreamSynchronize(s));

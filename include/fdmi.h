@@ -33,7 +33,8 @@ extern "C" {
 
 /* 2: fd_sample_steps_dev / fd_sample_end_dev return FD_E_STATE when another call has taken the run's workspace; history
  *    padding of packed rows is zeroed; head sizes other than 32 (multiples of 32) are accepted */
-#define FDMI_ABI_VERSION 2
+/* 3: fd_shift_trim_dev, fd_test_wrap, option "fuse_attn" (round 5) */
+#define FDMI_ABI_VERSION 3
 
 enum {
   FD_OK = 0,
@@ -120,6 +121,10 @@ void fd_destroy(fd_model* m);
  *                positions < lens[b] are bit-identical either way.  Padded positions of the final `out` then keep x_init;
  *                padded positions of history rows are zero.
  *                0 (default): every position evolves as in the reference's p_sample_loop.
+ *   "fuse_attn"  FD_PREC_F16X3, head size 32, d_model 384 / 192, 96 < L <= 128: BertSelfAttention of a sequence (q | k | v
+ *                projection + attention, modelling.py:473-480 -> HF BertSelfAttention.forward) as ONE kernel, q / k / v never
+ *                reach HBM.  -1 (default): when the batch fills whole rounds of the device's CUs; 1: whenever the shape allows;
+ *                0: never (the q|k|v GEMM + attention kernels).  The results are bit-identical either way.
  *   "split_qkv"  FD_PREC_F16X3: 1 = project q | k and v^T in two launches even when n_heads % 6 == 0 would allow one
  *                (A/B measurements, tests); 0 (default).
  *   "debug_stop" n > 0: a step returns after its first n launches (FD_PREC_F16X3; stage-by-stage comparison with
