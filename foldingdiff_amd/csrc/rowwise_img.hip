@@ -507,8 +507,12 @@ void launch_build_rows(const int* lens, int B, int L, int packed, int cap, int* 
     }                                                                                                           \
   } while (0)
 
-static int row_grid(int max_rows, int lpt) {  // blocks of the grid-stride row kernels (each block first fills its LDS parameter image)
-  static const int cap = [] { const char* e = getenv("FDMI_ROW_GRID"); return e ? atoi(e) : 1024; }();
+// blocks of the grid-stride row kernels (each block first fills its LDS parameter image).  def_cap: 1024 measured best for the head
+// kernel (16 lanes per row) and the LayerNorm kernel, 512 for the embed kernel (8 lanes per row: 33.5 us against 36.1 at C2,
+// profiles/r05_seq_attn_notes.log); FDMI_ROW_GRID overrides all of them
+static int row_grid(int max_rows, int lpt, int def_cap = 1024) {
+  static const int env_cap = [] { const char* e = getenv("FDMI_ROW_GRID"); return e ? atoi(e) : 0; }();
+  const int cap = env_cap > 0 ? env_cap : def_cap;
   const int per = 256 / lpt;
   int grid = (max_rows + per - 1) / per;
   return grid > cap ? cap : (grid < 1 ? 1 : grid);
@@ -521,7 +525,7 @@ static int row_lpt(int d, int F) {  // F > 0: the head kernel (one lane per outp
 }
 
 void launch_embed_img(const EmbedImgArgs& a, int max_rows, hipStream_t s) {
-  const int lpt = row_lpt(a.d, 0), nv = (a.d / 8 + lpt - 1) / lpt, grid = row_grid(max_rows, lpt);
+  const int lpt = row_lpt(a.d, 0), nv = (a.d / 8 + lpt - 1) / lpt, grid = row_grid(max_rows, lpt, lpt == 8 ? 512 : 1024);
   const size_t smem = (size_t)(a.F + 4) * a.d * 4;
   FD_ROW_SWITCH(embed_img_kernel, a);
 }

@@ -157,12 +157,15 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   unsigned char* Es = smem + OFF_E;
-  unsigned char* Ks = smem + OFF_K;
-  unsigned char* Vt = smem + OFF_V;
-  unsigned char* Rw = smem + OFF_R + wq * 8192;
-  unsigned char* Wr = smem + OFF_W;
   float* par = reinterpret_cast<float*>(smem + OFF_B);
-  const unsigned rw_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)(Rw));
+  // the LDS address of `smem` as an opaque scalar: every LDS address below is this + a constant + lane arithmetic.  Formed from the
+  // generic pointer at its point of use, an address costs the pointer cast's null check (seven scalar instructions), and hipcc
+  // re-forms addresses inside the item loop rather than keep them in registers
+  unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  asm volatile("" : "+s"(smem0));
+  const unsigned a_Es = smem0 + OFF_E, a_Ks = smem0 + OFF_K, a_Vt = smem0 + OFF_V, a_Rw = smem0 + OFF_R + (unsigned)(wq * 8192),
+                 a_Wr = smem0 + OFF_W, a_par = smem0 + OFF_B;
+  const unsigned rw_lds = a_Rw;
 
   // ---- once per workgroup: bias at the scale of the image its column feeds ((acc os + b) sc == fma(acc, os sc, b sc) exactly for the
   // power-of-two sc: gemm_img.hip), the distance table (attention_img.hip, ELDS: LDS row rho holds table row clamp(rho - esh))
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   // an immediate offset.  Odd pairs have the slots swapped (lower tile in slot 1): the same address + 4096, wrapped around the wave's
   // 8 KiB scratch (which is 8 KiB aligned) -- one add and one and-or per score instead of a sixteen-register address table, which
   // this kernel cannot afford (attention_img.hip keeps the table).
-  const unsigned gb = lds_addr(Rw) + (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31);
+  const unsigned gb = a_Rw + (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31);
   const unsigned gwrap = (unsigned)((l31 - 4 * half + 4) * 128 + 4 * l31) + 4096u;  // offset inside the scratch, before wrapping
-  const unsigned rw_base = lds_addr(Rw);
+  const unsigned rw_base = a_Rw;
   static_assert(OFF_R % 8192 == 0, "the skew scratch of a wave must be 8 KiB aligned");
   // band tile operand rows (attention_img.hip, ELDS): MFMA row l31 -> band row pi31 of the tile; unit u of LDS row rp sits at position
   // u ^ ((rp >> 1) & 7).  The lane's four units 2 k + half, k = 0..3, differ from unit `half` in bits 1-2 only, and the XOR commutes:
@@ -201,20 +204,20 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   unsigned eaddr0;
   {
     const int rp = p.maxpos - LP + esh + 32 * wq + pi31;
-    eaddr0 = lds_addr(Es) + (unsigned)(rp * 128 + ((half ^ ((rp >> 1) & 7)) << 4));
+    eaddr0 = a_Es + (unsigned)(rp * 128 + ((half ^ ((rp >> 1) & 7)) << 4));
     asm volatile("" : "+v"(eaddr0));
   }
   // K / V addresses of this lane: key (row) 32 wq + l31 of the head's K tile, feature row l31 of the V^T blocks
   const int ksz = (l31 >> 3) & 1;
   // the lane's units 2 c + 4 plane + half sit at positions (2 c + 4 plane + half) ^ ksz = 2 c + 4 plane + (half ^ ksz): the lane part
   // is folded into the base, the rest is an immediate offset
-  const unsigned k_rd = lds_addr(Ks) + (unsigned)((l31 >> 3) * 1024 + (l31 & 7) * 16 + ((half ^ ksz) << 7));  // + 4096 t + (2 c + 4 plane) * 128
+  const unsigned k_rd = a_Ks + (unsigned)((l31 >> 3) * 1024 + (l31 & 7) * 16 + ((half ^ ksz) << 7));  // + 4096 t + (2 c + 4 plane) * 128
   const unsigned k_wr = k_rd + (unsigned)(wq * 4096);
   const int vsz = vt_swz(l31);
-  const unsigned v_rd = lds_addr(Vt) + (unsigned)(l31 * 128);  // + 4096 t + ((unit ^ vsz) << 3)
+  const unsigned v_rd = a_Vt + (unsigned)(l31 * 128);  // + 4096 t + ((unit ^ vsz) << 3)
   const unsigned v_wr = v_rd + (unsigned)(wq * 4096);
-  const unsigned par_base = __builtin_amdgcn_readfirstlane(lds_addr(par));
-  const unsigned w_rd = lds_addr(Wr) + (unsigned)(l31 * 16 + half * 1536);  // + slot * KT_BYTES + (2 c + 4 plane) * 1536 + 512 j
+  const unsigned par_base = a_par;
+  const unsigned w_rd = a_Wr + (unsigned)(l31 * 16 + half * 1536);  // + slot * KT_BYTES + (2 c + 4 plane) * 1536 + 512 j
 
   const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
   const float mask_raw = -10000.0f * kLog2e / s_scale;                  // (1 - mask) * -10000 at the raw scale (modelling.py:452)
@@ -230,12 +233,15 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.wimg), 0, H * NKT * KT_BYTES, 0x00020000);
   // (the stream simply runs on past the workgroup's last position: what it requests there lands in free slots and is never read)
-  auto issue_w = [&]() __attribute__((always_inline)) {
-    const lds_ptr_t dst = (lds_ptr_t)(Wr) + __builtin_amdgcn_readfirstlane(w_slot);
+  // WRAP: the position requested is k-tile 0 of a head (stage NKT - 3 of an item requests it): only there can the stream have
+  // reached the end of the weight image
+  auto issue_w = [&](auto WRAP) __attribute__((always_inline)) {
+    if constexpr (decltype(WRAP)::value) w_src = w_src == H * NKT * KT_BYTES ? 0 : w_src;
+    const lds_ptr_t dst = (lds_ptr_t)(unsigned long long)(a_Wr + (unsigned)__builtin_amdgcn_readfirstlane(w_slot));
     const int so = __builtin_amdgcn_readfirstlane(w_src);
 #pragma unroll
     for (int k = 0; k < 3; ++k) dma16(rs_w, dst + (wq + 4 * k) * 1024, lane * 16, so + (wq + 4 * k) * 1024);
-    w_src = w_src + KT_BYTES == H * NKT * KT_BYTES ? 0 : w_src + KT_BYTES;
+    w_src += KT_BYTES;
     w_slot = w_slot + KT_BYTES == NST * KT_BYTES ? 0 : w_slot + KT_BYTES;
   };
 
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     for (int k = 0; k < 4; ++k) {
 #ifdef FDMI_SA_OLD_E
       const int rp = p.maxpos - LP + esh + 32 * wq + pi31;
-      e[k] = lds_u128(lds_addr(Es) + (unsigned)(rp * 128 + (((2 * k + half) ^ ((rp >> 1) & 7)) << 4)) + (unsigned)(qq * 4096));
+      e[k] = lds_u128(a_Es + (unsigned)(rp * 128 + (((2 * k + half) ^ ((rp >> 1) & 7)) << 4)) + (unsigned)(qq * 4096));
 #else
       e[k] = lds_u128((eaddr0 ^ (unsigned)(32 * k)) + (unsigned)(qq * 4096));
 #endif
@@ -728,9 +734,9 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) acc[j] = zero16;
   oacc = zero16;
-  issue_w();
-  issue_w();
-  issue_w();
+  issue_w(IC<0>{});
+  issue_w(IC<0>{});
+  issue_w(IC<0>{});
   FD_WAIT_VM(6);  // the first stage (and the hidden state, requested before it) landed
   barrier_keep_vm();
   proj_first();
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     FD_STAMP(kt);
     FD_WAIT_VM(3);
     barrier_keep_vm();
-    issue_w();
+    issue_w(IC<(kt == NKT - 3)>{});
     FD_SB();
     static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
       proj_mfma(KT, K);
@@ -766,6 +772,10 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
     const bool reload = real && head == H - 1 && seq + (int)gridDim.x < p.B;
     const int n_row0 = reload ? sload(p.seq_row0, seq + (int)gridDim.x) : 0;
     const bool after_reload = real && head == 0 && it > 0;
+    // (one item in six; an opaque scalar, or hipcc takes the test apart again into the two it came from: the common case is then
+    // one compare and one branch that is not taken per stage)
+    int special = __builtin_amdgcn_readfirstlane((reload || after_reload) ? 1 : 0);
+    asm volatile("" : "+s"(special));
     static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
       constexpr int kt = decltype(KT)::value;
       FD_STAMP(kt);
@@ -774,16 +784,15 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       // pieces of the stage after it, the 4 ctx stores of stage 2 (seen from the tops of stages 3 and 4), and -- while the hidden
       // state is being re-loaded -- the 4 loads issued at the end of the two stages before this one
       constexpr int ST = (SPS == 1 && (kt == 3 || kt == 4)) ? 4 : 0;  // (d_model 192: the stores leave in stage 1; the plain count only waits longer)
-      if (reload) {
-        FD_WAIT_VM(3 + ST + (kt == 0 ? 0 : (kt == 1 ? 4 : 8)));
-      } else if (after_reload) {
-        FD_WAIT_VM(3 + ST + (kt == 0 ? 8 : (kt == 1 ? 4 : 0)));
+      if (__builtin_expect(special != 0, 0)) {
+        if (reload) FD_WAIT_VM(3 + ST + (kt == 0 ? 0 : (kt == 1 ? 4 : 8)));
+        else FD_WAIT_VM(3 + ST + (kt == 0 ? 8 : (kt == 1 ? 4 : 0)));
       } else {
         FD_WAIT_VM(3 + ST);
       }
       barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
       if constexpr (kt == 0) FD_STAMP(15);  // (instrumented build: stage 0 in pieces -- barrier | copy-out, slot -1 | slots 0-6 | 7-12 | 13-17)
-      issue_w();
+      issue_w(IC<(kt == NKT - 3)>{});
       if constexpr (kt == 0) {  // the finished head's accumulators leave the matrix registers: its epilogue runs under this stage
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
