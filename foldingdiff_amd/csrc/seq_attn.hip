@@ -17,12 +17,16 @@
 //    ONE workgroup barrier per stage;
 //  * per head the epilogue turns the three 32 x 32 accumulators into: q_h -> this wave's B operand registers (bias, scale, hi / lo
 //    split, one half-wave exchange); k_h -> LDS in the attention kernel's unit-major piece layout; v_h -> LDS as V^T blocks;
-//  * the attention of head h-1 is SOFTWARE PIPELINED into the twelve stages of head h's projection (slices, see attn_slice): with
+//  * the attention of head h-1 is SOFTWARE PIPELINED into the twelve stages of head h's projection (slots, see attn_slot): with
 //    one wave per SIMD there is no partner wave to hide a dependent chain behind (S^T -> band -> softmax -> P V -> store), so every
-//    link of that chain sits one stage (~1000 cycles) behind the previous one and the matrix instructions of the projection fill
-//    the softmax / skew arithmetic's issue slots (plain fp32 VALU issues beside the matrix pipe: this file is compiled with
-//    -fno-slp-vectorize).  A sequence is 13 iterations: projection of head 0 alone, 11 fused ones, attention of head 11 alone
-//    (during which the next sequence's hidden state is fetched).
+//    link of that chain sits one stage (1100-2000 cycles) behind the previous one and the softmax / skew arithmetic sits between
+//    the projection's matrix instructions (plain fp32 VALU: this file is compiled with -fno-slp-vectorize).  The workgroup's
+//    (sequence, head) items form ONE stream: iteration i projects item i and runs the attention of item i - 1, across sequence
+//    boundaries too (the next sequence's hidden state replaces the current one in place, k-tile by k-tile, during the last head);
+//    only the first item's projection and the last item's attention -- once per launch -- are code of their own.
+//  * what bounds it (profiles/r05_seq_attn_notes.log): every stage fits T = 32 cycles x MFMAs + ~4 cycles x (VALU + LDS
+//    instructions) -- a wave's own vector work does not overlap its own matrix instructions; 294 MFMAs + ~1850 other instructions per
+//    item = 18.5 k cycles, 45 % of the matrix pipe.
 // Wave-uniform branches inside the fused iteration would split the stage into separately scheduled blocks, so every wave always
 // computes all 128 query / key rows: rows beyond the sequence's rows are finite garbage whose keys get -inf scores (probability
 // exactly 0) and whose ctx stores fall outside the buffer descriptor (dropped by the hardware).
