@@ -48,6 +48,9 @@
 #define FDMI_SA_EDGES 1  // 1: the first item's projection and the last item's attention run alone (their own code); 0: one loop body
                          // for everything -- iteration 0 runs an attention on garbage, the last one a projection for nothing
 #endif
+#ifndef FDMI_SA_SUBSTAGE
+#define FDMI_SA_SUBSTAGE 0  // instrumented build (FDMI_STAMPS=1): the stage whose pieces get stamps of their own
+#endif
 #ifndef FDMI_SA_DBG
 #define FDMI_SA_DBG 0  // ablation builds (wrong results): 1 = no attention slices, 2 = no projection MFMAs, 4 = no ctx stores
 #endif
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
         FD_WAIT_VM(3 + ST);
       }
       barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
-      if constexpr (kt == 0) FD_STAMP(15);  // (instrumented build: stage 0 in pieces -- barrier | copy-out, slot -1 | slots 0-6 | 7-12 | 13-17)
+      if constexpr (kt == FDMI_SA_SUBSTAGE) FD_STAMP(15);  // (instrumented build: one stage in pieces -- barrier | copy-out, slot -1 | slots 0-6 | 7-12 | 13-17)
       issue_w(IC<(kt == NKT - 3)>{});
       if constexpr (kt == 0) {  // the finished head's accumulators leave the matrix registers: its epilogue runs under this stage
 #pragma unroll
@@ -807,14 +810,14 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(SeqAttnArgs p) {
       FD_SB();
       attn_at(KT, IC<-1>{}, prev_head);
       FD_SB();
-      if constexpr (kt == 0) FD_STAMP(12);
+      if constexpr (kt == FDMI_SA_SUBSTAGE) FD_STAMP(12);
       static_for<0, 18>([&](auto K) __attribute__((always_inline)) {
         proj_mfma(KT, K);
         if constexpr (FDMI_SA_SCHED == 0) FD_SB();
         attn_at(KT, K, prev_head);
         if constexpr (FDMI_SA_SCHED == 0) FD_SB();
-        if constexpr (kt == 0 && decltype(K)::value == 6) FD_STAMP(13);
-        if constexpr (kt == 0 && decltype(K)::value == 12) FD_STAMP(14);
+        if constexpr (kt == FDMI_SA_SUBSTAGE && decltype(K)::value == 6) FD_STAMP(13);
+        if constexpr (kt == FDMI_SA_SUBSTAGE && decltype(K)::value == 12) FD_STAMP(14);
       });
       if constexpr (FDMI_SA_SCHED != 0) {
         // behind every MFMA (their source order stands): a few VALU, one transcendental, two scalar, one LDS read, one LDS write

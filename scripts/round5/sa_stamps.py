@@ -45,5 +45,7 @@ for w in (0, 3):
         tot = int(nxt - r[0]) if nxt else 0
         print(f"  it {i:2d}: " + " ".join(f"{v:5d}" for v in d) + f" {last:6d} | {tot:7d}")
         if r[12] and r[13] and r[14] and r[15]:  # stage 0 in pieces (main-loop iterations only)
-            pcs = [r[15] - r[0], r[12] - r[15], r[13] - r[12], r[14] - r[13], r[1] - r[14]]
-            print("         stage 0: wait+barrier %d | issue, copy-out, slot -1 %d | slots 0-6 %d | slots 7-12 %d | slots 13-17 %d" % tuple(int(v) for v in pcs))
+            ss = int(os.environ.get("SUBSTAGE", "0"))  # the stage the library was built to stamp in pieces (-DFDMI_SA_SUBSTAGE)
+            end = r[ss + 1] if ss < 11 else nxt
+            pcs = [r[15] - r[ss], r[12] - r[15], r[13] - r[12], r[14] - r[13], end - r[14]]
+            print("         stage %d: wait+barrier %d | issue, copy-out, slot -1 %d | slots 0-6 %d | slots 7-12 %d | slots 13-17 %d" % ((ss,) + tuple(int(v) for v in pcs)))
