@@ -521,3 +521,106 @@ def test_weight_stationary_gemm_deals_every_group_to_every_slice_exactly_once():
                             seen[(g, cb)] = b
             assert len(seen) == NT * nb, (N, NT, len(seen))
             assert idle == 8 * (per - S * nslice)
+
+
+def test_shift_trim_host_path_is_the_reference_arithmetic():
+    """N2 on host tensors (sampling._shift_trim's numpy branch: the CPU stand-in of the multi-process tests; the device branch is
+    fd_shift_trim_dev, GPU-tested against the same statements): /root/reference/foldingdiff/sampling.py:200-222 restated literally --
+    trim every item to its length, `s + offset` in numpy's promoted dtype, modulo_with_wrapped_range on the angular columns."""
+    rng = np.random.RandomState(5)
+    rows, B, L, F = 3, 5, 17, 6
+    traj = torch.from_numpy((rng.randn(rows, B, L, F) * 2.5).astype(np.float32))
+    lengths = [17, 1, 9, 16, 4]
+    angular = np.array([0, 1, 2, 4])          # a non-angular column in between: bond-angle-like features stay unwrapped
+    for offset in (None, (rng.randn(F) * 1.3).astype(np.float32), rng.randn(F) * 1.3):
+        got = sampling._shift_trim(None, traj, lengths, offset, angular)
+        want = [traj[:, i, :l, :].numpy() for i, l in enumerate(lengths)]                       # sampling.py:201-203
+        if offset is not None:                                                                 # sampling.py:218-222
+            want = [s + offset for s in want]
+            for s in want:
+                s[..., angular] = utils.modulo_with_wrapped_range(s[..., angular], range_min=-np.pi, range_max=np.pi)
+        assert len(got) == B
+        for g, w in zip(got, want):
+            assert g.shape == w.shape and g.dtype == w.dtype, (g.dtype, w.dtype)
+            assert np.array_equal(g, w)
+        if offset is not None:
+            assert all(np.all(g[..., angular] >= -np.pi) and np.all(g[..., angular] < np.pi) for g in got)
+            assert any(np.abs(g[..., 3]).max() > np.pi for g in got)   # the other column really is left alone
+
+
+@pytest.mark.parametrize("nkt,nseq", [(12, 1), (12, 2), (12, 3), (6, 1), (6, 4)])
+def test_fused_attention_stream_protocol(nkt, nseq):
+    """The vector-memory protocol of sa::seq_attn_kernel (seq_attn.hip), restated and simulated for one wave: the weight stream's
+    source offsets (wrap test only where a head's k-tile 0 is requested), its ring slots, and the counted stage-top waits.  vmcnt
+    retires in issue order, so `s_waitcnt vmcnt(n)` at the top of stage p guarantees everything but the n youngest operations; the
+    kernel needs the three LDS-DMA pieces of stage p + 1 landed there (it prefetches that stage's first fragments at the end of stage
+    p) and must not wait for more than that: the youngest operations are the pieces of stage p + 2, the four ctx stores of the
+    attention slice that holds them, and -- while the next sequence's hidden state replaces the current one in place -- the four loads
+    issued at the end of each of the two stages before.  The table restated here is the one in the kernel's item loop."""
+    H, NST, KT = nkt, 4, 96 * 128
+    sps = 12 // nkt
+    store_stage = 2 if sps == 1 else 1          # the stage whose attention slice stores the ctx block of the head before
+    nitems = nseq * H
+    total = H * nkt * KT
+    q = []                                      # issue order: ("w", stage) x3 | ("st", stage) x4 | ("h", stage) x4 | ("h0",) x 4 nkt
+    state = dict(w_src=0, w_slot=0, pos_req=0)
+    src_of, slot_of = {}, {}
+
+    def issue_w(wrapchk):
+        if wrapchk and state["w_src"] == total:
+            state["w_src"] = 0
+        p = state["pos_req"]
+        src_of[p], slot_of[p] = state["w_src"], state["w_slot"]
+        q.extend([("w", p)] * 3)
+        state["w_src"] += KT
+        state["w_slot"] = 0 if state["w_slot"] + KT == NST * KT else state["w_slot"] + KT
+        state["pos_req"] = p + 1
+
+    def check_wait(n, pos, exact):
+        """after vmcnt(n) at the top of stage `pos`: the pieces of stage pos + 1 have landed; `exact`: and n is not smaller than needed"""
+        last = max(i for i, op in enumerate(q) if op == ("w", pos + 1))
+        younger = len(q) - 1 - last
+        assert n <= younger, (pos, n, younger)   # the wait covers the pieces of stage pos + 1
+        if exact:
+            assert n == younger, (pos, n, younger)
+
+    q.extend([("h0",)] * (4 * nkt))
+    for _ in range(3):
+        issue_w(False)
+    # FD_WAIT_VM(6): stage 0 (and the hidden state in front of it) landed
+    assert len(q) - 1 - max(i for i, op in enumerate(q) if op == ("w", 0)) == 6
+    pos = 0
+    for kt in range(nkt):                       # iteration 0: the first item's projection alone
+        check_wait(3, pos, exact=True)
+        issue_w(kt == nkt - 3)
+        pos += 1
+    head, seq = 1, 0
+    for it in range(1, nitems):
+        reload = head == H - 1 and seq + 1 < nseq
+        after_reload = head == 0
+        for kt in range(nkt):
+            st = 4 if (sps == 1 and kt in (3, 4)) else 0
+            if reload:
+                n = 3 + st + (0 if kt == 0 else (4 if kt == 1 else 8))
+            elif after_reload:
+                n = 3 + st + (8 if kt == 0 else (4 if kt == 1 else 0))
+            else:
+                n = 3 + st
+            # d_model 192 (two slices per stage): the stores leave in stage 1 and the plain count waits for them too -- correct, not exact
+            exact = sps == 1 or kt not in (store_stage + 1, store_stage + 2)
+            check_wait(n, pos, exact=exact)
+            issue_w(kt == nkt - 3)
+            if kt == store_stage:
+                q.extend([("st", pos)] * 4)
+            if reload:
+                q.extend([("h", pos)] * 4)
+            pos += 1
+        head += 1
+        if head == H:
+            head, seq = 0, seq + 1
+    # every requested position is (head, k-tile) of the image in order, wrapping after the last head; a stage's slot is its position mod NST
+    for p in range(state["pos_req"]):
+        assert src_of[p] == (p % (H * nkt)) * KT, (p, src_of[p])
+        assert slot_of[p] == (p % NST) * KT
+    # a slot is only overwritten after the stage that read it: position p + NST is requested at the top of stage p + 1 (>= p + 1)
+    assert state["pos_req"] == nitems * nkt + 3
