@@ -557,6 +557,13 @@ def test_fused_attention_stream_protocol(nkt, nseq):
     p) and must not wait for more than that: the youngest operations are the pieces of stage p + 2, the four ctx stores of the
     attention slice that holds them, and -- while the next sequence's hidden state replaces the current one in place -- the four loads
     issued at the end of each of the two stages before.  The table restated here is the one in the kernel's item loop."""
+    src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "seq_attn.hip")).read()
+    for stmt in ("constexpr int ST = (SPS == 1 && (kt == 3 || kt == 4)) ? 4 : 0;",          # the table simulated below IS the kernel's
+                 "if (reload) FD_WAIT_VM(3 + ST + (kt == 0 ? 0 : (kt == 1 ? 4 : 8)));",
+                 "else FD_WAIT_VM(3 + ST + (kt == 0 ? 8 : (kt == 1 ? 4 : 0)));",
+                 "FD_WAIT_VM(3 + ST);", "FD_WAIT_VM(6);", "issue_w(IC<(kt == NKT - 3)>{});",
+                 "constexpr int NST = 4;", "constexpr int KT_BYTES = 96 * 128;"):
+        assert stmt in src, stmt
     H, NST, KT = nkt, 4, 96 * 128
     sps = 12 // nkt
     store_stage = 2 if sps == 1 else 1          # the stage whose attention slice stores the ctx block of the head before
