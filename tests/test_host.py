@@ -631,3 +631,42 @@ def test_fused_attention_stream_protocol(nkt, nseq):
         assert slot_of[p] == (p % NST) * KT
     # a slot is only overwritten after the stage that read it: position p + NST is requested at the top of stage p + 1 (>= p + 1)
     assert state["pos_req"] == nitems * nkt + 3
+
+
+def test_fused_attention_weight_image_matches_the_fragment_reads():
+    """The contract between api.hip (upload_seq_attn_weights: the q|k|v weights as [head][k-tile][unit 0-7][96 rows q_h | k_h | v_h][16 B],
+    a (head, k-tile) = one 12 KiB ring stage byte for byte) and seq_attn.hip's fragment reads (rd_w: lane (l31, half) reads 16 bytes at
+    stage + (unit + half) * 1536 + j * 512 + l31 * 16 for accumulator j, unit = 2 c + 4 plane): every read must deliver the eight
+    k-consecutive fp16 values W[j d + 32 head + l31][32 kt + 16 c + 8 half + 0..7] of the plane -- the A operand slice of
+    v_mfma_f32_32x32x16_f16 for MFMA row l31.  Both formulas restated; the source lines they restate are pinned."""
+    root = os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc")
+    api, sa = open(os.path.join(root, "api.hip")).read(), open(os.path.join(root, "seq_attn.hip")).read()
+    for stmt in ("const int n = (r / 32) * d + h * 32 + (r % 32);", "memcpy(stage + ((size_t)u * 96 + r) * 8, blk + u * 8, 16);"):
+        assert stmt in api, stmt
+    for stmt in ("const unsigned w_rd = a_Wr + (unsigned)(l31 * 16 + half * 1536);", "lds_u128(wb + (unsigned)(unit * 1536 + j * 512))",
+                 "rd_w(Xw, 0);", "rd_w(Yw, 4);", "rd_w(Xw, 2);", "rd_w(Yw, 6);"):
+        assert stmt in sa, stmt
+    for d in (384, 192):
+        nk = H = d // 32
+        # the row-major split image (pack_split_weight): per (weight row n, k-tile) 64 halves = units 0-3 hi k 0..31, units 4-7 lo
+        # element id = (plane, n, k) so that a read can be checked by value
+        def rm_block(n, kt):
+            return [(u // 4, n, 32 * kt + 8 * (u % 4) + e) for u in range(8) for e in range(8)]
+        for h in (0, 1, H - 1):
+            for kt in (0, nk - 1):
+                stage = [None] * (96 * 64)
+                for r in range(96):
+                    n = (r // 32) * d + h * 32 + (r % 32)
+                    blk = rm_block(n, kt)
+                    for u in range(8):
+                        stage[(u * 96 + r) * 8: (u * 96 + r) * 8 + 8] = blk[u * 8: u * 8 + 8]
+                assert all(v is not None for v in stage)
+                for j in range(3):
+                    for l31 in range(32):
+                        for half in range(2):
+                            for unit in (0, 4, 2, 6):            # hi c0, lo c0, hi c1, lo c1: the four rd_w calls of a stage
+                                c, plane = (unit % 4) // 2, unit // 4
+                                byte = (unit + half) * 1536 + j * 512 + l31 * 16
+                                got = stage[byte // 2: byte // 2 + 8]
+                                want = [(plane, j * d + 32 * h + l31, 32 * kt + 16 * c + 8 * half + e) for e in range(8)]
+                                assert got == want, (d, h, kt, j, l31, half, unit)
