@@ -151,7 +151,7 @@ def _run_fd_sample_streamed(model, h, x0: np.ndarray, lens: np.ndarray, t_start:
         _NOISE_BUFFERS[key] = ([torch.empty((nrow, B, L, F), dtype=torch.float32).pin_memory() for _ in range(2)],
                                [torch.empty((nrow, B, L, F), dtype=torch.float32, device=dev) for _ in range(2)],
                                torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-    pinned, dbuf, copy_s, run_s = _NOISE_BUFFERS[key]
+    pinned, dbuf, copy_s, run_s = _NOISE_BUFFERS[key] = _NOISE_BUFFERS.pop(key)  # (re-inserted: the dict's order is the order of last use)
     copied = [torch.cuda.Event(), torch.cuda.Event()]
     consumed = [None, None]
     x_d = torch.from_numpy(x0).to(dev)
