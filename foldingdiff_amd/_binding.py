@@ -17,7 +17,7 @@ FD_DEC = {"mlp": 0, "linear": 1}
 FD_PREC_F32 = 0
 FD_PREC_F16X3 = 1
 FD_PREC = {"f32": 0, "f16x3": 1}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FdmiError(RuntimeError):
@@ -77,6 +77,7 @@ _SIGNATURES = {
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fd_synchronize": (C.c_int, [_P]),
     "fd_check_finite": (C.c_int, [_P]),
+    "fd_fused_attn_supported": (C.c_int, [_P, C.c_int]),
     "fd_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "fd_last_error": (C.c_char_p, []),
 }

@@ -54,7 +54,8 @@ struct LayerDev {
   // row-image path: weight images padded to 384 rows, and the (static, power-of-two) scales of this layer's
   // activation images -- derived from norm bounds of the weights at fd_finalize, so nothing can overflow fp16
   SplitW wqk_i, wv_i, wqkv_i, wo_i, wi_i, wd_i;  // wqkv_i: q | k | v rows in one image (n_heads % 6 == 0: one launch)
-  SplitW wsa_i;  // the same q | k | v weights ordered per head for the fused projection + attention kernel (seq_attn.hip), or null
+  SplitW wsa_i;  // the same q | k | v weights ordered per head for the 32-row fused projection + attention kernel (seq_attn.hip), or null
+  SplitW wsa16_i;  // ... for the 16-row kernel (seq_attn16.hip: rows of a head permuted into its operand tiles), or null
   float *bqk = nullptr, *bv = nullptr;  // bias slices of bqkv
   float s_h = 1.f, s_q = 1.f, s_k = 1.f, s_v = 1.f, s_a = 1.f, s_g = 1.f;
   float *wqkv = nullptr, *bqkv = nullptr, *demb = nullptr;
@@ -248,6 +249,34 @@ int upload_seq_attn_weights(fd_model* m, SplitW* dst, const float* W, int d) {
         const uint16_t* blk = rm.data() + ((size_t)n * nk + kt) * 64;
         for (int u = 0; u < 8; ++u) memcpy(stage + ((size_t)u * 96 + r) * 8, blk + u * 8, 16);
       }
+    }
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, img.size() * 2));
+  m->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  dst->p = p;
+  return FD_OK;
+}
+
+// seq_attn16.hip's weights: [head][k32 step][tile: q 0, q 1, k 0, k 1, v 0, v 1][unit 0-7][row 0-15][16 B] (a k32 step of a head = 12 KiB,
+// two of them = one LDS ring stage byte for byte; a tile = one v_mfma_f32_16x16x32_f16 operand, unit-major).  Row i of tile j holds
+// head feature 8 (i / 4) + 4 j + (i % 4): with that order the 16 x 16 C/D layout gives every lane eight consecutive features of its
+// token (seq_attn16.hip).  Split at the SAME scale as wqkv_i.
+int upload_seq_attn16_weights(fd_model* m, SplitW* dst, const float* W, int d) {
+  std::vector<uint16_t> rm, img;
+  pack_split_weight(W, 3 * d, d, &rm, &dst->scale, 384);
+  const int nk = d / 32, H = d / 32;
+  img.assign((size_t)H * nk * 96 * 64, 0);
+  for (int h = 0; h < H; ++h)
+    for (int kt = 0; kt < nk; ++kt) {
+      uint16_t* step = img.data() + ((size_t)h * nk + kt) * 96 * 64;
+      for (int t = 0; t < 6; ++t)
+        for (int i = 0; i < 16; ++i) {
+          const int f = 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
+          const int n = (t >> 1) * d + h * 32 + f;
+          const uint16_t* blk = rm.data() + ((size_t)n * nk + kt) * 64;
+          for (int u = 0; u < 8; ++u) memcpy(step + (size_t)t * 1024 + ((size_t)u * 16 + i) * 8, blk + u * 8, 16);
+        }
     }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, img.size() * 2));
@@ -693,32 +722,44 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
   for (int li = 0; li < c.n_layers; ++li) {
     const LayerDev& lw = m->layers[li];
     const float s_next = li + 1 < c.n_layers ? m->layers[li + 1].s_h : m->s_hfinal;
-    // q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): q, k and v never reach HBM
+    // q | k | v projection + attention as ONE kernel per sequence: q, k and v never reach HBM.  fuse_attn: 1 = seq_attn16.hip (16-row
+    // waves, two per SIMD; any L <= 128, padded or packed rows), 2 = seq_attn.hip (round 5: 32-row waves, 96 < L <= 128), 0 = never
     static const int fuse_attn_env = [] { const char* e = getenv("FDMI_FUSE_ATTN"); return e ? atoi(e) : -1; }();
     const int fuse_attn = m->fuse_attn >= 0 ? m->fuse_attn : fuse_attn_env;
-    // auto: padded rows only, and only when the batch fills whole rounds of the CUs (one workgroup = one sequence at a time: 512
-    // sequences on 256 CUs are two full rounds, 300 would leave the second round four-fifths empty and 8 sequences would run on 8 CUs)
-    bool fused_auto = !m->varlen;
-    if (fused_auto) {
+    // auto: when the batch fills whole rounds of the CUs (one workgroup = one sequence at a time: 512 sequences on 256 CUs are two full
+    // rounds, 300 would leave the second round four-fifths empty and 8 sequences would run on 8 CUs)
+    bool fused_auto = false;
+    {
       const int ncu = gemm_img_grid(1 << 30, 384);  // (= the CU count, rounded down to whole XCDs)
       const int rounds = (B + ncu - 1) / ncu;
       fused_auto = (double)B >= 0.94 * (double)rounds * ncu;
     }
-    const bool fused_attn = lw.wsa_i.p && fuse_attn != 0 && (fuse_attn > 0 || fused_auto) && !mode.kmask && !m->split_qkv &&
-                            seq_attn_supported(d, c.n_heads, L, c.max_pos) && (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
+    const bool fused_ok = fuse_attn != 0 && (fuse_attn > 0 || fused_auto) && !mode.kmask && !m->split_qkv &&
+                          (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
+    const bool fused16 = fused_ok && fuse_attn != 2 && lw.wsa16_i.p && seq_attn16_supported(d, c.n_heads, L, c.max_pos);
+    const bool fused32 = fused_ok && !fused16 && (fuse_attn == 2 || fuse_attn < 0) && lw.wsa_i.p && (fuse_attn == 2 || !m->varlen) &&
+                         seq_attn_supported(d, c.n_heads, L, c.max_pos);
+    const bool fused_attn = fused16 || fused32;
     if (fused_attn) {
       SeqAttnArgs a;
       memset(&a, 0, sizeof a);
       a.himg = w.himg; a.himg_bytes = (unsigned)((size_t)w.cap * d * 4);
-      a.wimg = static_cast<const unsigned char*>(lw.wsa_i.p); a.bias = lw.bqkv;
+      const SplitW& wsa = fused16 ? lw.wsa16_i : lw.wsa_i;
+      a.wimg = static_cast<const unsigned char*>(wsa.p); a.bias = lw.bqkv;
       a.demb = static_cast<const u32x4_t*>(lw.demb_s.p);
       a.lens = w.lens; a.nrow = w.nrow; a.seq_row0 = w.seq_row0; a.ctx = w.cimg;
       a.B = B; a.H = H; a.maxpos = c.max_pos;
-      a.acc_scale = 1.0f / (lw.s_h * lw.wsa_i.scale);
+      a.acc_scale = 1.0f / (lw.s_h * wsa.scale);
       a.q_scale = lw.s_q; a.k_scale = lw.s_k; a.v_scale = lw.s_v; a.ctx_scale = lw.s_v;
       a.r_scale = lw.s_k / lw.demb_s.scale;
       a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 + 4 * 64 * 8 : nullptr;
-      PROF(KC_SEQ_ATTN, launch_seq_attn(a, s));
+      if (fused16) {
+        bool launched = false;
+        PROF(KC_SEQ_ATTN, launched = launch_seq_attn16(a, s));
+        if (!launched) return fail(FD_E_HIP, "the fused projection + attention kernel could not be launched (%d bytes of LDS per workgroup)", 160256);
+      } else {
+        PROF(KC_SEQ_ATTN, launch_seq_attn(a, s));
+      }
       DBG_STOP();
       DBG_STOP();  // (two launches of the other path: debug_stop counts stay comparable)
     } else if (lw.wqkv_i.p && !m->split_qkv) {
@@ -1264,6 +1305,9 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
       lw.wsa_i = SplitW();
       if (c.pos_type == FD_POS_RELATIVE_KEY && seq_attn_supported((int)d, c.n_heads, c.max_pos < 128 ? c.max_pos : 128, c.max_pos))
         if (int rc = upload_seq_attn_weights(m, &lw.wsa_i, wqkv.data(), (int)d)) return rc;
+      lw.wsa16_i = SplitW();
+      if (c.pos_type == FD_POS_RELATIVE_KEY && seq_attn16_supported((int)d, c.n_heads, c.max_pos < 128 ? c.max_pos : 128, c.max_pos))
+        if (int rc = upload_seq_attn16_weights(m, &lw.wsa16_i, wqkv.data(), (int)d)) return rc;
       lw.bqk = lw.bqkv;
       lw.bv = lw.bqkv + 2 * d;
       lw.s_h = scale_for(hb.linf);
@@ -1353,7 +1397,7 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   if (n == "fuse_ln") m->fuse_ln = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
   else if (n == "varlen") m->varlen = value ? 1 : 0;
-  else if (n == "fuse_attn") m->fuse_attn = value < 0 ? -1 : (value ? 1 : 0);
+  else if (n == "fuse_attn") m->fuse_attn = value < 0 ? -1 : (value > 2 ? 1 : value);
   else if (n == "split_qkv") {
     m->split_qkv = value ? 1 : 0;
     drop_workspaces(m);  // captured graphs hold the other launch sequence
@@ -1365,6 +1409,16 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   else if (n == "debug_layer") m->debug_layer = value;
   else return fail(FD_E_INVALID, "unknown option '%s'", name);
   return FD_OK;
+}
+
+int fd_fused_attn_supported(fd_model* m, int L) {
+  if (!m) return fail(FD_E_INVALID, "null argument");
+  if (!m->finalized) return fail(FD_E_STATE, "fd_finalize has not been called");
+  if (m->precision != FD_PREC_F16X3 || m->layers.empty() || L < 1) return 0;
+  const fd_config& c = m->cfg;
+  const LayerDev& lw = m->layers[0];
+  if (m->fuse_attn == 2) return lw.wsa_i.p && seq_attn_supported(c.d_model, c.n_heads, L, c.max_pos) ? 1 : 0;
+  return lw.wsa16_i.p && seq_attn16_supported(c.d_model, c.n_heads, L, c.max_pos) ? 1 : 0;
 }
 
 int fd_forward(fd_model* m, const float* x, int t, const int32_t* lens, int B, int L, float* eps_out) {

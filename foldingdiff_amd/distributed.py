@@ -2,7 +2,9 @@
 Multi-GPU sampling: independent sequences are sharded across the GPUs of one
 node, every rank runs the whole reverse process on its slice with NO per-step
 communication, and a single collective returns the final angles to rank 0
-(RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).
+(RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests):
+``gather_final`` for equal-shaped [b, L, F] blocks (bench.py), ``gather_ragged`` for the
+already trimmed per-item buffers of ``sampling.sample`` (to rank 0, or to every rank on request).
 
 The reference has no multi-GPU sampler (foldingdiff/sampling.py is single
 device, :91); this is the MI355X-native extension SURVEY 8(e) specifies.
@@ -77,6 +79,8 @@ def all_gather_batches(local: torch.Tensor, counts: Sequence[int], device=None, 
     home = local.device
     if dist.get_backend(group) == "nccl":
         local = local.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    elif local.is_cuda:   # gloo has no CUDA collectives here
+        local = local.cpu()
     bmax = max(counts)
     pad = local
     if local.shape[0] != bmax:
@@ -86,6 +90,36 @@ def all_gather_batches(local: torch.Tensor, counts: Sequence[int], device=None, 
     dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
     out = out.view((world, bmax) + tuple(local.shape[1:]))
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0).to(home)
+
+
+def gather_ragged(local: torch.Tensor, sizes: Sequence[int], device=None, to_all: bool = False, group=None) -> Optional[List[torch.Tensor]]:
+    """ONE collective over flat float32 blocks of different sizes: rank r contributes ``sizes[r]`` elements (every rank knows
+    every size: they follow from the lengths and the shard bounds).  ``to_all=False``: a gather to rank 0 -- rank 0 gets the
+    list of the world's blocks in rank order (views of one receive buffer), every other rank ``None`` and receives nothing;
+    ``to_all=True``: an all-gather, every rank gets the list.  Under "nccl" (= RCCL over xGMI) the blocks travel from HBM
+    to HBM on ``device``; under "gloo" a CUDA block is taken to the host first (gloo has no CUDA collectives here)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(sizes) == world and local.dim() == 1 and local.numel() == sizes[rank], (local.shape, sizes, rank)
+    if dist.get_backend(group) == "nccl":
+        local = local.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    elif local.is_cuda:
+        local = local.cpu()
+    nmax = max(max(sizes), 1)
+    pad = local
+    if local.numel() != nmax:   # equal-sized slots: one collective instead of world point-to-point messages
+        pad = torch.zeros((nmax,), dtype=local.dtype, device=local.device)
+        pad[: local.numel()] = local
+    pad = pad.contiguous()
+    if to_all:
+        out = torch.empty((world * nmax,), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
+    else:
+        out = torch.empty((world * nmax,), dtype=local.dtype, device=local.device) if rank == 0 else None
+        dist.gather(pad, list(out.view(world, nmax).unbind(0)) if rank == 0 else None, dst=0, group=group)
+        if rank != 0:
+            return None
+    return [out[r * nmax: r * nmax + sizes[r]] for r in range(world)]
 
 
 def any_rank_failed(failed: bool, device=None, group=None) -> bool:

@@ -377,7 +377,8 @@ def sample(
     trim_to_length: bool = True,
     final_only: bool = False,
     history_every: int = 1,
-) -> List[np.ndarray]:
+    gather: str = "rank0",
+) -> Optional[List[np.ndarray]]:
     """Sample ``n`` backbones per length in ``range(*sweep_lengths)`` (upper bound
     exclusive) -- or ``n`` backbones with lengths from ``train_dset.sample_length()``
     when ``sweep_lengths`` is None.  Returns one array per backbone of shape
@@ -395,9 +396,16 @@ def sample(
     Multi-GPU (extension; the reference is single device): when ``torch.distributed`` is initialised -- e.g.
     ``torchrun bin/sample.py`` with one process per GPU -- every rank draws the same start / step noise (same torch
     seed, as a replicated run of the reference would), runs the reverse process on a token-balanced slice of each
-    batch only, and ONE all-gather per batch gives every rank the complete result, identical to a single-GPU run."""
+    batch only, cuts / shifts / re-wraps ITS OWN slice on its own device, and ONE collective per batch moves the
+    already trimmed (ragged) blocks: ``gather="rank0"`` (default) to rank 0 only -- rank 0 returns the complete list,
+    identical to a single-GPU run, every other rank returns ``None`` (SURVEY 8e: "a single RCCL gather ... at the end");
+    ``gather="all"`` to every rank (every rank returns the complete list: world x the bytes, e.g. 1.57 GB per 512
+    sequences per rank with the full history); ``gather="none"``: no exchange, every rank returns its own items only
+    (in batch order)."""
     from . import distributed as fdist
 
+    if gather not in ("rank0", "all", "none"):
+        raise ValueError(f"gather={gather!r}: expected 'rank0', 'all' or 'none'")
     if sweep_lengths is not None:
         lo, hi = sweep_lengths
         if not lo < hi:
@@ -424,6 +432,11 @@ def sample(
         logging.info(f"Shifting predicted values by original offset: {offset}")
     angular = np.asarray(train_dset.feature_is_angular[feature_key], dtype=bool)
     on_gpu = _run_fd_sample is _run_fd_sample_default and getattr(getattr(model, "device", None), "type", "") == "cuda"
+    # every rank finalises the model for THIS schedule and THIS angular mask before the first batch: the trim kernel reads
+    # the mask of the finalised model, and a rank whose slice of a batch is empty never reaches p_sample_loop
+    model.prepare(train_dset.alpha_beta_terms["betas"], train_dset.feature_is_angular[feature_key])
+    rows = 1 if final_only else -(-T // history_every)
+    F = model.n_inputs
     results: List[np.ndarray] = []
     for start in range(0, len(lengths), batch_size):
         these = lengths[start : start + batch_size]
@@ -444,9 +457,9 @@ def sample(
             raise ValueError(f"NOISE_MODE={NOISE_MODE!r}")
         bounds = fdist.shard_by_tokens(these, world) if world > 1 else [(0, B)]
         lo, hi = bounds[rank]
-        rows = 1 if final_only else -(-T // history_every)
         home = model.device if on_gpu else torch.device("cpu")  # where a batch's stored states live until they are trimmed
         local_error = None
+        flat = None
         if hi > lo:
             prev_varlen = model.set_option("varlen", 1)
             try:
@@ -455,36 +468,45 @@ def sample(
                     betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
                     disable_pbar=disable_pbar, final_only=final_only, history_every=history_every,
                     seed=seed, seq_offset=lo, draw_batch=(B, lo, hi), _device_out=on_gpu)
+                # this rank's items, cut to their lengths, shifted and re-wrapped where they are (the device), as one ragged buffer
+                flat = _shift_trim_flat(model, traj, these[lo:hi], offset, angular)
+                del traj
             except Exception as e:  # e.g. FD_E_NONFINITE from this rank's slice: every rank must learn of it before the gather
                 if world == 1:
                     raise
                 local_error = e
-                traj = torch.zeros((rows, hi - lo, L, F), dtype=torch.float32, device=home)
             finally:
                 model.set_option("varlen", prev_varlen if prev_varlen is not None else 0)
-        else:
-            if NOISE_MODE == "torch":  # an empty shard still advances the generator exactly as the other ranks do
-                _StepNoise(T - 1, (B, L, F), (0, 0)).materialize()
-            traj = torch.zeros((rows, 0, L, F), dtype=torch.float32, device=home)
-        if world > 1:  # the single exchange of the path: [b_r, rows, L, F] blocks -> every rank holds the whole batch
+        elif NOISE_MODE == "torch":  # an empty shard still advances the generator exactly as the other ranks do
+            _StepNoise(T - 1, (B, L, F), (0, 0)).materialize()
+        if flat is None:
+            flat = torch.zeros((0,), dtype=torch.float32, device=home)   # an empty slice, or a failed one (reported just below)
+        if world > 1:
             device = getattr(model, "device", torch.device("cpu"))
             failed = fdist.any_rank_failed(local_error is not None, device)   # one tiny all-reduce: all ranks abort together
             if failed:
                 raise RuntimeError(f"rank {rank}: sampling failed on " + ("this rank: " + repr(local_error) if local_error else "another rank"))
-            # (device-resident blocks stay on the device through the collective: RCCL reads and writes HBM directly)
-            full = fdist.all_gather_batches(traj.permute(1, 0, 2, 3).contiguous(), [h_ - l_ for l_, h_ in bounds], device)
-            traj = full.permute(1, 0, 2, 3).contiguous()
-        results.extend(_shift_trim(model, traj, these, offset, angular))
+            if gather != "none":
+                # the single exchange of the path: the ragged, already trimmed blocks in rank order = the batch in item order
+                # (device-resident blocks stay on the device through the collective: RCCL reads and writes HBM directly)
+                sizes = [rows * sum(these[l_:h_]) * F for l_, h_ in bounds]
+                flat = fdist.gather_ragged(flat, sizes, device, to_all=(gather == "all"))
+                if flat is None:   # gather="rank0" on another rank
+                    continue
+                lo, hi = 0, B
+        results.extend(_split_items(flat, these[lo:hi], rows, F, offset, angular))
+    if world > 1 and gather == "rank0" and rank != 0:
+        return None
     return results
 
 
-def _shift_trim(model, traj: torch.Tensor, lengths: Sequence[int], offset: Optional[np.ndarray], angular: np.ndarray) -> List[np.ndarray]:
-    """The tail of the reference's ``sample`` (foldingdiff/sampling.py:200-222) for one batch: item i = the first
-    ``lengths[i]`` positions of every stored state, plus the training mean offset, angular features re-wrapped to
-    [-pi, pi).  ``traj``: [rows, B, L, F].  A CUDA tensor is processed by ``fd_shift_trim_dev`` (one launch, one ragged
-    device-to-host copy; the arrays returned are views of that buffer); a float32 offset is applied there with the
-    reference's float32 arithmetic (bit-identical), any other offset dtype after the copy, vectorised over the whole buffer
-    in numpy's promoted dtype -- exactly what ``s + offset`` gives in the reference."""
+def _shift_trim_flat(model, traj: torch.Tensor, lengths: Sequence[int], offset: Optional[np.ndarray], angular: np.ndarray) -> torch.Tensor:
+    """The tail of the reference's ``sample`` (foldingdiff/sampling.py:200-222) for a block of items, as ONE ragged float32
+    buffer on ``traj``'s device: item i = the first ``lengths[i]`` positions of every stored state ([rows, len_i, F],
+    contiguous, items in order), plus the training mean offset, angular features re-wrapped to [-pi, pi).  ``traj``:
+    [rows, B, L, F].  A CUDA tensor is processed by ``fd_shift_trim_dev`` (one launch).  Only a float32 offset is applied
+    here, with the reference's float32 arithmetic (bit-identical); any other offset dtype is applied by ``_split_items`` on
+    the host copy in numpy's promoted dtype -- exactly what ``s + offset`` gives in the reference."""
     rows, B, L, F = traj.shape
     assert B == len(lengths)
     sizes = np.array([rows * int(l) * F for l in lengths], dtype=np.int64)
@@ -503,19 +525,44 @@ def _shift_trim(model, traj: torch.Tensor, lengths: Sequence[int], offset: Optio
                                              C.c_void_p(item_off.data_ptr()), o32.ctypes.data_as(C.c_void_p) if o32 is not None else None,
                                              C.c_void_p(out_d.data_ptr()), None))
         _binding.check(lib.fd_synchronize(h))
-        flat = out_d.cpu().numpy()
-    else:  # host tensors (the CPU stand-in of the multi-process tests): the same ragged buffer, assembled with numpy
-        t = traj.numpy()
-        flat = np.concatenate([t[:, i, : int(l), :].reshape(-1) for i, l in enumerate(lengths)]) if B else np.zeros((0,), np.float32)
-        if off32:
-            flat = flat.reshape(-1, F) + np.asarray(offset)
-            flat[:, angular] = utils.modulo_with_wrapped_range(flat[:, angular], range_min=-np.pi, range_max=np.pi)
-            flat = flat.reshape(-1)
-    if offset is not None and not off32:  # e.g. a float64 offset file: numpy promotes, as in the reference
+        return out_d
+    # host tensors (the CPU stand-in of the multi-process tests): the same ragged buffer, assembled with numpy
+    t = traj.numpy()
+    flat = np.concatenate([t[:, i, : int(l), :].reshape(-1) for i, l in enumerate(lengths)]) if B else np.zeros((0,), np.float32)
+    if off32:
+        flat = flat.reshape(-1, F) + np.asarray(offset)
+        flat[:, angular] = utils.modulo_with_wrapped_range(flat[:, angular], range_min=-np.pi, range_max=np.pi)
+        flat = flat.reshape(-1)
+    return torch.from_numpy(np.ascontiguousarray(flat))
+
+
+def _split_items(flat, lengths: Sequence[int], rows: int, F: int, offset: Optional[np.ndarray], angular: np.ndarray) -> List[np.ndarray]:
+    """One ragged device-to-host copy of ``_shift_trim_flat``'s buffer (a tensor, or a list of per-rank pieces in item
+    order) and its items as views of the host buffer: [rows, len_i, F] each."""
+    sizes = np.array([rows * int(l) * F for l in lengths], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    if isinstance(flat, (list, tuple)):   # the pieces of a gather: each one copied straight to its place (no device concat)
+        host = np.empty((int(offs[-1]),), dtype=np.float32)
+        at = 0
+        for piece in flat:
+            host[at: at + piece.numel()] = piece.cpu().numpy()
+            at += piece.numel()
+        assert at == host.size
+        flat = host
+    else:
+        flat = flat.cpu().numpy()
+    assert flat.size == int(offs[-1])
+    if offset is not None and np.asarray(offset).dtype != np.float32:  # e.g. a float64 offset file: numpy promotes, as in the reference
         flat = flat.reshape(-1, F) + np.asarray(offset)
         flat[:, angular] = utils.modulo_with_wrapped_range(flat[:, angular], range_min=-np.pi, range_max=np.pi)
         flat = flat.reshape(-1)
     return [flat[offs[i]: offs[i + 1]].reshape(rows, int(l), F) for i, l in enumerate(lengths)]
+
+
+def _shift_trim(model, traj: torch.Tensor, lengths: Sequence[int], offset: Optional[np.ndarray], angular: np.ndarray) -> List[np.ndarray]:
+    """``_shift_trim_flat`` + ``_split_items``: [rows, B, L, F] stored states -> one [rows, len_i, F] array per item."""
+    rows, _, _, F = traj.shape
+    return _split_items(_shift_trim_flat(model, traj, lengths, offset, angular), lengths, rows, F, offset, angular)
 
 
 @torch.no_grad()

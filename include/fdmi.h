@@ -34,7 +34,9 @@ extern "C" {
 /* 2: fd_sample_steps_dev / fd_sample_end_dev return FD_E_STATE when another call has taken the run's workspace; history
  *    padding of packed rows is zeroed; head sizes other than 32 (multiples of 32) are accepted */
 /* 3: fd_shift_trim_dev, fd_test_wrap, option "fuse_attn" (round 5) */
-#define FDMI_ABI_VERSION 3
+/* 4: fd_fused_attn_supported; option "fuse_attn" takes 2 (the round-5 kernel) and its default kernel no longer promises the bits of
+ *    the two-kernel path (round 6) */
+#define FDMI_ABI_VERSION 4
 
 enum {
   FD_OK = 0,
@@ -121,15 +123,23 @@ void fd_destroy(fd_model* m);
  *                positions < lens[b] are bit-identical either way.  Padded positions of the final `out` then keep x_init;
  *                padded positions of history rows are zero.
  *                0 (default): every position evolves as in the reference's p_sample_loop.
- *   "fuse_attn"  FD_PREC_F16X3, head size 32, d_model 384 / 192, 96 < L <= 128: BertSelfAttention of a sequence (q | k | v
+ *   "fuse_attn"  FD_PREC_F16X3, relative_key, head size 32, d_model 384 / 192, L <= 128: BertSelfAttention of a sequence (q | k | v
  *                projection + attention, modelling.py:473-480 -> HF BertSelfAttention.forward) as ONE kernel, q / k / v never
- *                reach HBM.  -1 (default): when the batch fills whole rounds of the device's CUs; 1: whenever the shape allows;
- *                0: never (the q|k|v GEMM + attention kernels).  The results are bit-identical either way.
+ *                reach HBM.  -1 (default): when the batch fills whole rounds of the device's CUs; 1: whenever the shape allows
+ *                (fd_fused_attn_supported); 0: never (the q|k|v GEMM + attention kernels); 2: the round-5 kernel (32-row waves,
+ *                96 < L <= 128; kept for A/B measurements).  Every choice meets the same tolerance against the reference
+ *                (1e-5 on the forward, 1e-3 rad on a step); 0 and 2 give the same bits as each other, 1 does not (it sums in
+ *                another order).
  *   "split_qkv"  FD_PREC_F16X3: 1 = project q | k and v^T in two launches even when n_heads % 6 == 0 would allow one
  *                (A/B measurements, tests); 0 (default).
  *   "debug_stop" n > 0: a step returns after its first n launches (FD_PREC_F16X3; stage-by-stage comparison with
  *                fd_debug_read, scripts/debug_img.py); "debug_layer": which encoder layer fd_debug_read sees. */
 int fd_set_option(fd_model* m, const char* name, int value);
+
+/* 1 if option "fuse_attn" = 1 (or 2, when that is the current value) runs the fused projection + attention kernel for batches of
+ * padded length L on this (finalized) model, 0 if the q|k|v GEMM + attention kernels run instead; negative: FD_E_*.  No reference
+ * counterpart (HF BertSelfAttention.forward is one code path); tests use it to know which kernels a gate exercised. */
+int fd_fused_attn_supported(fd_model* m, int L);
 
 /* ---- parity hooks ---- */
 

@@ -1,5 +1,5 @@
 """Worker of tests/test_distributed.py::test_two_gpu_rccl_* (one process per GPU, launched with torch.distributed.run):
-sampling.sample over RCCL must return on EVERY rank exactly what a single process returns, and the C-ABI collective
+sampling.sample over RCCL must return on rank 0 (gather="all": on EVERY rank) exactly what a single process returns, and the C-ABI collective
 (fd_comm_init / fd_gather_dev) must gather device blocks in rank order."""
 import ctypes as C
 import os
@@ -32,7 +32,9 @@ def main():
         timesteps=12, beta_schedule="cosine")
     sampling.NOISE_MODE = "philox"
     torch.manual_seed(11)
-    got = sampling.sample(pm, ds, n=2, sweep_lengths=(60, 66), batch_size=7, disable_pbar=True)   # sharded: one all-gather per batch
+    got = sampling.sample(pm, ds, n=2, sweep_lengths=(60, 66), batch_size=7, disable_pbar=True)   # sharded: one gather to rank 0 per batch
+    torch.manual_seed(11)
+    got_all = sampling.sample(pm, ds, n=2, sweep_lengths=(60, 66), batch_size=7, disable_pbar=True, gather="all")
     # the same call as a single process would run it (no process group visible to sample())
     saved = sampling._dist_world
     sampling._dist_world = lambda: (1, 0)
@@ -41,9 +43,11 @@ def main():
         want = sampling.sample(pm, ds, n=2, sweep_lengths=(60, 66), batch_size=7, disable_pbar=True)
     finally:
         sampling._dist_world = saved
-    assert len(got) == len(want) == 12
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and np.array_equal(a, b)
+    assert (got is None) == (rank != 0)          # default: the result lives on rank 0 only
+    for res in ([got] if rank == 0 else []) + [got_all]:
+        assert len(res) == len(want) == 12
+        for a, b in zip(res, want):
+            assert a.shape == b.shape and np.array_equal(a, b)
     # the C-ABI collective: every rank contributes a block of its own size pattern; rank order in the result
     lib = _binding.load()
     h = pm._ensure_handle()

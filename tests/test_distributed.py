@@ -100,40 +100,36 @@ def _stub_fd_sample(h, x0, lens, t_start, zs, seed, seq_offset, out, full_histor
     out[:] = np.where(real, val, np.nan)[None].astype(np.float32)   # padded positions must never reach a result
 
 
-def _run_sample(mode):
+def _run_sample(mode, gather="rank0", sweep=(5, 14), n=3, final_only=True, offset=None):
+    import numpy as np
     from foldingdiff_amd import datasets, sampling
     sampling._run_fd_sample = _stub_fd_sample
     sampling.NOISE_MODE = mode
-    ds = datasets.NoisedAnglesDataset(datasets.AnglesEmptyDataset("canonical-full-angles", pad=32), timesteps=4,
-                                      beta_schedule="cosine")
+    ds = datasets.NoisedAnglesDataset(
+        datasets.AnglesEmptyDataset("canonical-full-angles", pad=32, mean_offset=None if offset is None else np.asarray(offset)),
+        timesteps=4, beta_schedule="cosine")
     torch.manual_seed(11)
     model = _StubModel()
-    res = sampling.sample(model, ds, n=3, sweep_lengths=(5, 14), batch_size=16, final_only=True)
+    res = sampling.sample(model, ds, n=n, sweep_lengths=sweep, batch_size=16, final_only=final_only, gather=gather)
     return res, model.opts
 
 
-def _sample_worker(rank, world, port, mode, q):
+def _sample_worker(rank, world, port, mode, q, kw):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res, opts = _run_sample(mode)
-        q.put((rank, [r.copy() for r in res], opts))
+        res, opts = _run_sample(mode, **kw)
+        q.put((rank, None if res is None else [r.copy() for r in res], opts))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["torch", "philox"])
-def test_sample_is_sharded_and_world_size_invariant(mode):
-    import numpy as np
-    want, opts1 = _run_sample(mode)                     # single process: torch.distributed not initialised
-    assert len(want) == 27 and [w.shape for w in want] == [(1, 5 + i // 3, 6) for i in range(27)]
-    assert all(np.isfinite(w).all() for w in want)
-    assert opts1 == [("varlen", 1), ("varlen", 0)] * 2  # two batches (16 + 11), padded positions not computed
+def _two_ranks(mode, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, mode, q, kw)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict()
@@ -143,10 +139,61 @@ def test_sample_is_sharded_and_world_size_invariant(mode):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank in (0, 1):                                  # every rank holds the complete, identical result
+    return got
+
+
+@pytest.mark.parametrize("mode", ["torch", "philox"])
+def test_sample_is_sharded_and_world_size_invariant(mode):
+    """Default exchange: ONE gather of the trimmed blocks to rank 0 -- rank 0 holds the complete result,
+    identical to the single-process one; the other rank receives nothing and returns None."""
+    import numpy as np
+    want, opts1 = _run_sample(mode)                     # single process: torch.distributed not initialised
+    assert len(want) == 27 and [w.shape for w in want] == [(1, 5 + i // 3, 6) for i in range(27)]
+    assert all(np.isfinite(w).all() for w in want)
+    assert opts1 == [("varlen", 1), ("varlen", 0)] * 2  # two batches (16 + 11), padded positions not computed
+    got = _two_ranks(mode)
+    assert got[1] is None
+    assert len(got[0]) == 27
+    for a, b in zip(got[0], want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_sample_gather_all_and_none_with_history_and_offsets():
+    """gather="all": the complete result on every rank (the opt-in former behaviour); gather="none": every rank keeps its own
+    items, together they are the single-process list.  With the stored history (rows > 1) and a float64 mean offset (applied on
+    the host copy in numpy's promoted dtype, as the reference's ``s + offset`` does)."""
+    import numpy as np
+    off = np.array([0.3, -1.2, 3.0, 0.0, 1.9, -2.5], dtype=np.float64)
+    kw = dict(final_only=False, offset=off)
+    want, _ = _run_sample("philox", **kw)
+    assert want[0].shape == (4, 5, 6) and want[0].dtype == np.float64
+    got = _two_ranks("philox", gather="all", **kw)
+    for rank in (0, 1):
         assert len(got[rank]) == 27
         for a, b in zip(got[rank], want):
-            assert a.shape == b.shape and np.array_equal(a, b)
+            assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
+    got = _two_ranks("philox", gather="none", **kw)
+    assert 0 < len(got[0]) < 27 and len(got[0]) + len(got[1]) == 27
+    # batch 1 = items 0..15, batch 2 = items 16..26; each rank holds a contiguous slice of each
+    n0 = [len(got[0]), len(got[1])]
+    shapes = sorted(a.shape for r in (0, 1) for a in got[r])
+    assert shapes == sorted(w.shape for w in want)
+    pool = {w.tobytes() for w in want}
+    assert all(a.tobytes() in pool for r in (0, 1) for a in got[r]), n0
+
+
+@pytest.mark.parametrize("mode", ["torch", "philox"])
+def test_sample_with_fewer_items_than_ranks(mode):
+    """One item on two ranks: shard_by_tokens gives one rank an empty slice (cuts [0, 0, 1] or [0, 1, 1]); that rank never
+    reaches the sampler, still takes part in the exchange, and the result is the single-process one."""
+    import numpy as np
+    kw = dict(sweep=(9, 10), n=1)
+    want, _ = _run_sample(mode, **kw)
+    assert len(want) == 1 and want[0].shape == (1, 9, 6)
+    got = _two_ranks(mode, **kw)
+    assert got[1] is None and len(got[0]) == 1 and np.array_equal(got[0][0], want[0])
+    got = _two_ranks(mode, gather="all", **kw)
+    assert all(len(got[r]) == 1 and np.array_equal(got[r][0], want[0]) for r in (0, 1))
 
 
 def _failing_worker(rank, world, port, q):
@@ -217,3 +264,21 @@ def test_two_gpu_rccl_sample_and_c_abi_gather():
     import json
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["dist"]["backend"] == "nccl" and line["config"]["global_batch"] == 128
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run with one process per
+    GPU (the first multi-GPU lease must produce a curve without new code).  Without a GPU every rank stops at the
+    device check -- reaching it inside a worker of the elastic agent is the proof that the launcher ran."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher (on a GPU box the -m gpu RCCL test runs the real thing)")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs torch.distributed.run" not in r.stderr
+    # (the elastic agent ends the other rank as soon as one has failed: at least one rank reports, and the agent's summary follows)
+    assert r.stderr.count("bench.py needs an MI355X") >= 1 and "local_rank" in r.stderr, r.stderr[-2000:]
