@@ -6,30 +6,38 @@
 // state alone is 192 registers), and one in-order wave cannot overlap its own vector / LDS work with its own matrix instructions:
 // 45 % of the matrix pipe.  Here a wave owns SIXTEEN token rows and every contraction runs on v_mfma_f32_16x16x32_f16:
 //   * 8 waves per workgroup = 2 per SIMD, 256 registers each: hidden state 96 (12 k32 steps x (hi, lo) x 4), projection
-//     accumulators 24 (q_h | k_h | v_h: six 16 x 16 tiles), weight fragments 48, the attention's state ~100;
-//   * the two waves of a SIMD fill each other's issue gaps (LDS round trips, dependent VALU chains, the softmax), which is what the
-//     one-wave kernel had to do by hand with a slot schedule;
+//     accumulators 24 (q_h | k_h | v_h: six 16 x 16 tiles), weight fragments 60, the attention's state ~100;
+//   * the two waves of a SIMD fill each other's issue gaps: in the projection both stream MFMAs from register fragments (the pipe is
+//     saturated: 72 MFMAs per stage and SIMD) while the LDS-DMA requests and the fragment reads of one hide behind the matrix
+//     instructions of the other (the two groups of waves request their pieces at opposite ends of a stage); in the attention the
+//     LDS round trips, the skew and the softmax of one wave sit beside the other's;
 //   * no half-wave exchanges at all: the weight rows of a head are PERMUTED in the weight image (tile j, row i = head feature
 //     8 (i / 4) + 4 j + (i % 4)), so that the 16 x 16 C/D layout (lane (c, g) holds rows 4 g .. 4 g + 3 of column c) hands every
 //     lane the eight consecutive features 8 g .. 8 g + 7 of its token -- exactly one 16-byte operand unit of the next contraction
 //     (Q^T as B operand, K rows as A operand, the ctx image's units); V^T and P^T share a permuted key order inside a 32-key step
 //     (kappa = 8 g + 4 p + e  <->  key 16 p + 4 g + e) for the same reason.
 // Arithmetic: the fp16 hi / lo split triples of gemm_img.hip / attention_img.hip (a product = hi hi + hi lo + lo hi, fp32
-// accumulate), in the same order per accumulator; the MFMA's K is 32 instead of 16, so sums are associated differently:
-// fp32-class results, NOT the bits of the two-kernel path (the oracle gates of tests/test_gpu_parity.py are the contract).
+// accumulate); the MFMA's K is 32 instead of 16, so sums are associated differently: fp32-class results, NOT the bits of the
+// two-kernel path (the oracle gates of tests/test_gpu_parity.py are the contract).
 //
-// Structure.  One workgroup per CU, persistent over sequences of <= 128 rows; wave w owns token rows 16 w .. 16 w + 15.
-//   per (sequence, head):
-//     projection   NKT k32 steps; the head's 96 weight rows stream through a 3-slot LDS ring in stages of two k32 steps (24 KiB,
-//                  LDS-DMA, three 1 KiB pieces per wave, ONE workgroup barrier per stage, counted s_waitcnt vmcnt: the stream
-//                  never drains); 36 MFMAs per wave and stage
+// Structure.  One workgroup per CU, persistent over sequences of <= 128 rows.  Wave (group, r) = wave 4 group + r owns the 16-row
+// block r + 4 ((r & 1) ^ group) of the sequence (blocks 0-3 of a short sequence land on four different SIMDs).
+//   per (sequence, head), all eight waves in step:
+//     projection   NS stages of two k32 steps; the head's 96 weight rows stream through a 3-slot LDS ring (24 KiB stages, LDS-DMA,
+//                  three 1 KiB pieces per wave, ONE workgroup barrier per stage, counted s_waitcnt vmcnt: the stream never drains);
+//                  per wave and stage 24 fragment reads (requested ahead of their MFMAs) and 36 MFMAs
 //     epilogue     bias, scale, hi / lo split: q_h -> this wave's operand registers, k_h -> LDS (A operand tiles), v_h -> LDS (V^T)
 //     barrier      (K and V^T of all eight waves are in place)
 //     attention    S^T = K Q^T (8 key tiles), the relative_key band R^T = E Q^T (9 band tiles of 16 distances, skewed through a 2 KiB
 //                  per-wave LDS scratch), mask, softmax in the log2 domain (row statistics: in-lane + two lane-group swaps),
-//                  O^T = V^T P^T, ctx block -> HBM (two 16-byte stores per lane)
-//   Key tiles / waves beyond the sequence's rows are skipped (wave-uniform branches: a second wave covers the bubbles), so short
-//   sequences (BASELINE C3, packed rows) cost what their rows cost.
+//                  O^T = V^T P^T, ctx block -> HBM (two 16-byte stores per lane) -- every piece an explicit software pipeline
+//                  (operands of group n + 1 requested while group n multiplies, sched_barriers between the steps): left alone hipcc
+//                  serialises the tiles to save registers, and the wave waits out every LDS round trip
+//   Other structures measured on the way (scripts/round6/README.md, profiles/r06_seq_attn16_notes.log): the two groups half a period
+//   apart (one projects while the other attends: the attending wave becomes the SIMD's critical path, every weight stage is streamed
+//   twice, and an LDS-DMA piece costs its issuer ~70 cycles -- 273-287 us against this file's figure).
+//   Key-range halves / waves beyond the sequence's rows are skipped (wave-uniform branches), so short sequences (BASELINE C3, packed
+//   rows) cost what their rows cost.
 #include <cstdlib>
 #include <type_traits>
 
@@ -63,7 +71,8 @@ __device__ __forceinline__ void sload4(const int* a, int ia, const int* b, int i
   asm volatile(
       "s_load_dword %0, %4, %5\n\ts_load_dword %1, %6, %7\n\ts_load_dword %2, %8, %9\n\ts_load_dword %3, %10, %11\n\ts_waitcnt lgkmcnt(0)"
       : "=&s"(x), "=&s"(y), "=&s"(z), "=&s"(w)
-      : "s"(a), "s"(ia * 4), "s"(b), "s"(ib * 4), "s"(c), "s"(ic * 4), "s"(d), "s"(id * 4)
+      : "s"(a), "s"(__builtin_amdgcn_readfirstlane(ia * 4)), "s"(b), "s"(__builtin_amdgcn_readfirstlane(ib * 4)), "s"(c),
+        "s"(__builtin_amdgcn_readfirstlane(ic * 4)), "s"(d), "s"(__builtin_amdgcn_readfirstlane(id * 4))
       : "memory");
 }
 
@@ -91,6 +100,23 @@ __device__ __forceinline__ float quad_sum(float x) {
   swap16(a, b);
   return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(IC<LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
+#ifndef FDMI_S16_DBG
+#define FDMI_S16_DBG 0  // ablation builds (WRONG results): 1 = the projection does not wait for its weight stages, 2 = no attention work,
+                        // 4 = no projection MFMAs
+#endif
+#ifndef FDMI_S16_PRIO
+#define FDMI_S16_PRIO 0  // > 0: s_setprio of a wave while it attends (its projecting partner on the SIMD runs at 0)
+#endif
 
 __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -121,16 +147,25 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, g = lane >> 4;
+  const int grp = wq >> 2, wr = wq & 3;
+  const int rb = wr + 4 * ((wr & 1) ^ grp);  // the 16-row block of the sequence this wave owns
   unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   asm volatile("" : "+s"(smem0));
-  const unsigned lane_off = (unsigned)(g * 256 + c * 16);  // unit g (hi; + 1024: lo unit 4 + g), row c of a 2 KiB operand tile
-  const unsigned a_E = smem0 + OFF_E + lane_off, a_K = smem0 + OFF_K + lane_off, a_V = smem0 + OFF_V + lane_off,
-                 a_W = smem0 + OFF_W + lane_off, a_R = smem0 + OFF_R + (unsigned)(wq * 2048), a_B = smem0 + OFF_B;
+  // Nothing derived from the lane index lives across the loops: every phase re-derives its lane coordinates (c = lane & 15: row /
+  // column of a 16 x 16 tile, g = lane >> 4: k group) and LDS addresses from an OPAQUE copy of the lane index.  As loop invariants
+  // hipcc keeps ~14 such values in scratch, and every reload sits behind a vmcnt(0) that drains the weight stream.
+  auto lane_id = [&]() __attribute__((always_inline)) {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    return ln;
+  };
+  // operand tile address inside a 2 KiB tile: unit g (hi; + 1024: lo unit 4 + g), row c
+  auto lane_off_of = [](int ln) __attribute__((always_inline)) { return (unsigned)((ln >> 4) * 256 + (ln & 15) * 16); };
+  static_assert(OFF_R % 2048 == 0, "the skew scratch of a wave must be 2 KiB aligned (slot swap = address ^ 1024)");
 
   // ---- once per workgroup: bias at the scale of the image its column feeds ((acc os + b) sc == fma(acc, os sc, b sc) exactly for the
-  // power-of-two sc), the distance table (LDS row e holds table row clamp(e - esh): e = l - r + 127), zeros in V^T (a skipped key
-  // tile's probabilities are exact zeros, and 0 x whatever the LDS held at power-on must not be NaN)
+  // power-of-two sc), the distance table (LDS row e holds table row clamp(e - esh): e = l - r + 127), zeros in K and V^T (a skipped key
+  // range's probabilities are exact zeros, and 0 x whatever the LDS held at power-on must not be NaN)
   {
     float* par = reinterpret_cast<float*>(smem + OFF_B);
     for (int i = tid; i < 3 * D; i += 64 * NW) {
@@ -150,17 +185,6 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
     for (int i = tid; i < 2048; i += 64 * NW) Vz[i] = u32x4{0u, 0u, 0u, 0u};
   }
 
-  // skew gather addresses (see the band below): score (query c, key 16 t + 4 g + e) of S^T tile t takes band row j = c - (4 g + e) + 15
-  // of the tile pair (t, t - 1): rows 0-15 are tile t (scratch slot t & 1), rows 16-30 tile t - 1 (the other slot).  A band tile in the
-  // scratch: row rho = 4 gg + ee of query cc at float index ee * 64 + gg * 16 + cc (= 4 x lane + 256 ee: the layout the C/D
-  // registers are written with).  gad[e]: the address for EVEN t; odd t: the slots are swapped, address ^ 1024
-  unsigned gad[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = c - (4 * g + e) + 15, rho = j & 15;
-    gad[e] = a_R + (unsigned)((j >= 16 ? 1024 : 0) + ((rho & 3) * 64 + (rho >> 2) * 16 + c) * 4);
-  }
-
   const float s_scale = kLog2e * kInvSqrtD / (p.q_scale * p.k_scale);  // raw MFMA sums -> log2 domain
   const float mask_raw = -10000.0f * kLog2e / s_scale;                  // (1 - mask) * -10000 at the raw scale (modelling.py:452)
   const float oss_q = p.acc_scale * p.q_scale, oss_k = p.acc_scale * p.k_scale, oss_v = p.acc_scale * p.v_scale;
@@ -174,8 +198,9 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
   auto issue_w = [&]() __attribute__((always_inline)) {
     const lds_ptr_t dst = (lds_ptr_t)(unsigned long long)(smem0 + OFF_W + (unsigned)__builtin_amdgcn_readfirstlane(w_slot));
     const int so = __builtin_amdgcn_readfirstlane(w_src);
+    const int vo = lane_id() * 16;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dma16(rs_w, dst + (wq + NW * k) * 1024, lane * 16, so + (wq + NW * k) * 1024);
+    for (int k = 0; k < 3; ++k) dma16(rs_w, dst + (wq + NW * k) * 1024, vo, so + (wq + NW * k) * 1024);
     w_src = w_src + STAGE == H * NS * STAGE ? 0 : w_src + STAGE;
     w_slot = w_slot + STAGE == NST * STAGE ? 0 : w_slot + STAGE;
   };
@@ -185,8 +210,9 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
   f16x8 hh[NKT], hl[NKT];
   const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.himg), 0, p.himg_bytes, 0x00020000);
   auto load_h = [&](int r0) __attribute__((always_inline)) {  // rows beyond the image read as zeros
-    const int row = r0 + 16 * wq + c;
-    const unsigned hoff = (unsigned)(((row >> 5) * (NKT * 256) + (row & 31)) * 16 + g * 512);
+    const int ln = lane_id();
+    const int row = r0 + 16 * rb + (ln & 15);
+    const unsigned hoff = (unsigned)(((row >> 5) * (NKT * 256) + (row & 31)) * 16 + (ln >> 4) * 512);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       hh[kt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, (int)hoff, kt * 8 * 512, 0));
@@ -198,6 +224,7 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
   unsigned long long* stp = PROF ? p.stamps + (size_t)wq * 32 * 16 : nullptr;
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 32 && lane == 0) stp[slot * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define FD_SB() __builtin_amdgcn_sched_barrier(0)
 
   int seq = blockIdx.x;
   if (seq >= p.B) return;
@@ -213,7 +240,8 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
   for (;;) {
     const int nrows = row1 - row0;
     const int nkt = (Lb + 15) >> 4;         // key tiles that hold a key at all
-    const bool active = 16 * wq < Lb;       // this wave owns rows of the sequence (wave-uniform)
+    const bool upper = nkt > 4;             // the sequence has keys beyond 64: work is skipped in halves of the key range
+    const bool active = 16 * rb < Lb;       // this wave owns rows of the sequence (wave-uniform)
     const int next_seq = seq + (int)gridDim.x;
     for (int head = 0; head < H; ++head) {
       // ================================================================ projection of head `head`
@@ -221,56 +249,115 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
       f32x4 acc[6];  // q tile 0, 1 | k tile 0, 1 (swapped form: lane = token) | v tile 0, 1 (normal form: lane = feature)
 #pragma unroll
       for (int t = 0; t < 6; ++t) acc[t] = zero4;
-#pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        // this stage landed (its three pieces of this wave; every wave says so at the barrier).  vmcnt retires in issue order: at
-        // most the pieces of the stage after this one may be outstanding -- and, at the first two tops of a head, the two ctx stores
-        // of the head before, which are younger than this stage's pieces
+      // The projection is a software pipeline over the head's NKT k32 steps: the twelve fragments of step ks + 1 are requested while
+      // step ks multiplies (two fragment buffers of 48 registers), across stage boundaries too -- the barrier that publishes stage j
+      // (= steps 2 j, 2 j + 1) sits at the START of step 2 j - 1, when every fragment of stage j - 1 is already in registers: that
+      // stage's ring slot is free for stage j + 2 right there, and the matrix instructions never wait for a barrier + LDS round trip
+      // except at the head's first step.  (gemm_img.hip hides its k-tile barrier the same way.)
+      // Stage tops: this stage landed (its three pieces of this wave; every wave says so at the barrier).  vmcnt retires in issue
+      // order: at most the pieces of the stage after this one may be outstanding -- and, at the first two tops of a head, the two ctx
+      // stores of the head before, which are younger than this stage's pieces.
+      // Two fragment buffers of six tiles (48 registers) alternate over the planes hi(0) lo(0) hi(1) lo(1) ...: while a plane multiplies
+      // (hi: 12 MFMAs, lo: 6) the next one is requested into the other buffer.  (72 or 96 registers of fragments made hipcc keep part
+      // of the hidden state in scratch, reloaded behind vmcnt(0): that drains the weight stream.)
+      f16x8 fx[6], fy[6];
+      unsigned a_W = smem0 + OFF_W + lane_off_of(lane_id());
+      // A stage top = this wave's pieces of the stage landed (vmcnt retires in issue order: at most the pieces of the stage after
+      // this one may be outstanding -- and, at the first two tops of a head, the two ctx stores of the head before, which are younger
+      // than this stage's pieces), workgroup barrier (they landed for every wave; every wave has READ the last fragment of the stage
+      // two before the one that is requested next, whose ring slot that request overwrites), request of the stage after next.
+      // The barrier that publishes stage j = steps 2 j, 2 j + 1 sits inside step 2 j - 1: behind that step's lo-plane reads (the
+      // last reads of stage j - 1) and in front of the reads of hi(2 j).
+      auto stage_wait_barrier = [&](auto ST) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value;
         if (st < 2) FD_WAIT_VM(5);
         else FD_WAIT_VM(3);
-        barrier_keep_vm();  // ... for every wave; every wave is done with the stage before: its slot is free
-        issue_w();
-        if (active) {
+        barrier_keep_vm();
+      };
+      auto plane_reads = [&](auto KS, auto LO, f16x8 (&f)[6]) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value, lo = decltype(LO)::value;
+        // ring slot of the stage that holds step ks: `pos` is the slot of the head's first stage
+        int off = pos + (ks >> 1) * STAGE;
+        off = off >= NST * STAGE ? off - NST * STAGE : off;
+        unsigned sb = a_W + (unsigned)(off + (ks & 1) * KS_BYTES + lo * 1024);
+        asm volatile("" : "+v"(sb));
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int kt = 2 * st + ks;
-            const unsigned wb = a_W + (unsigned)pos + (unsigned)(ks * KS_BYTES);
-            f16x8 wh[6], wl[6];
+        for (int t = 0; t < 6; ++t) f[t] = lds_f16x8(sb + (unsigned)(t * 2048));
+      };
+      // per accumulator: wh hh | wh hl | wl hh (gemm_img.hip's order); consecutive MFMAs never share an accumulator
+      auto mm_hh = [&](auto KS, const f16x8 (&fh)[6]) __attribute__((always_inline)) {
+        constexpr int kt = decltype(KS)::value;
 #pragma unroll
-            for (int t = 0; t < 6; ++t) wh[t] = lds_f16x8(wb + (unsigned)(t * 2048));
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fh[t], hh[kt], acc[t]);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) wl[t] = lds_f16x8(wb + (unsigned)(t * 2048 + 1024));
-            // per accumulator: wh hh | wh hl | wl hh (gemm_img.hip's order); consecutive MFMAs never share an accumulator
+        for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], fh[t], acc[t]);
+      };
+      auto mm_hl = [&](auto KS, const f16x8 (&fh)[6]) __attribute__((always_inline)) {
+        constexpr int kt = decltype(KS)::value;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma16(wh[t], hh[kt], acc[t]);
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fh[t], hl[kt], acc[t]);
 #pragma unroll
-            for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], wh[t], acc[t]);
+        for (int t = 4; t < 6; ++t) acc[t] = mfma16(hl[kt], fh[t], acc[t]);
+      };
+      auto mm_lh = [&](auto KS, const f16x8 (&fl)[6]) __attribute__((always_inline)) {
+        constexpr int kt = decltype(KS)::value;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma16(wh[t], hl[kt], acc[t]);
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fl[t], hh[kt], acc[t]);
 #pragma unroll
-            for (int t = 4; t < 6; ++t) acc[t] = mfma16(hl[kt], wh[t], acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma16(wl[t], hh[kt], acc[t]);
-#pragma unroll
-            for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], wl[t], acc[t]);
+        for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], fl[t], acc[t]);
+      };
+      // The head's first stage: published by a barrier of its own, its first hi plane read behind it (the one LDS round trip per head
+      // that the matrix pipe waits for)
+      stage_wait_barrier(IC<0>{});
+      issue_w();
+      // The two waves of a SIMD run the same instruction sequence; only the stage top (barrier + the three LDS-DMA requests, ~300
+      // cycles without a matrix instruction) sits at different places: group 0 has it in front of the step's twelve hi-plane MFMAs,
+      // group 1 behind them -- in the steady state group 1 runs twelve MFMAs ahead, and one wave's read bursts and requests sit beside
+      // the other's MFMAs instead of beside its own.  (Two different step sequences, branched per head or per step, made hipcc spill;
+      // so do activity tests around the pieces of a step: a wave without rows takes a path of its own, stage tops only.)
+      if (active) {
+        plane_reads(IC<0>{}, IC<0>{}, fx);
+        FD_SB();
+        static_for<0, NKT>([&](auto KS) __attribute__((always_inline)) {
+          constexpr int ks = decltype(KS)::value;
+          constexpr bool top = (ks & 1) == 1 && ks + 1 < NKT;  // this step carries the barrier that publishes the stage of steps ks + 1, ks + 2
+          plane_reads(KS, IC<1>{}, fy);
+          FD_SB();
+          if constexpr (top) {
+            if (grp == 0) { stage_wait_barrier(IC<(ks + 1) / 2>{}); issue_w(); }
           }
-        }
-        pos = pos + STAGE == NST * STAGE ? 0 : pos + STAGE;
-        FD_STAMP(1 + st);
+          mm_hh(KS, fx);
+          mm_hl(KS, fx);
+          FD_SB();
+          if constexpr (top) {
+            if (grp != 0) { stage_wait_barrier(IC<(ks + 1) / 2>{}); issue_w(); }
+          }
+          if constexpr (ks + 1 < NKT) plane_reads(IC<ks + 1>{}, IC<0>{}, fx);
+          FD_SB();
+          mm_lh(KS, fy);
+          FD_SB();
+          if constexpr ((ks & 1) == 1) FD_STAMP(1 + ks / 2);
+        });
+      } else {
+        static_for<1, NS>([&](auto ST) __attribute__((always_inline)) {
+          stage_wait_barrier(ST);
+          issue_w();
+        });
       }
-      // the hidden state is dead after the sequence's last projection: the next sequence's replaces it while this head's epilogue and
-      // attention run (the first row alone is read here; the other parameters of that sequence at the loop's end)
-      if (head == H - 1 && next_seq < p.B) {
-        int nr0, d0, d1, d2;
-        sload4(p.seq_row0, next_seq, p.seq_row0, next_seq, p.seq_row0, next_seq, p.seq_row0, next_seq, nr0, d0, d1, d2);
-        load_h(nr0);
-      }
+      pos = pos + NS * STAGE;
+      pos = pos >= 2 * NST * STAGE ? pos - 2 * NST * STAGE : (pos >= NST * STAGE ? pos - NST * STAGE : pos);
 
       f16x8 qh, ql;  // Q^T operand of the head: this lane's token, features 8 g .. 8 g + 7
+      qh = ql = __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
       if (active) {
         // ================================================================ epilogue: q_h -> registers, k_h -> LDS, v_h -> LDS
         // (same arithmetic as gemm_img.hip's q | k and v^T epilogues: fma(acc, os sc, b sc), then the split)
-        const unsigned bq = a_B + (unsigned)((head * 32 + 8 * g) * 4);
+        const int ln = lane_id();
+        const int c = ln & 15, g = ln >> 4;
+        const unsigned a_B = smem0 + OFF_B;
+        unsigned bq = a_B + (unsigned)((head * 32 + 8 * g) * 4);
+        unsigned aKw = smem0 + OFF_K + lane_off_of(ln) + (unsigned)(rb * 2048),
+                 aVw = smem0 + OFF_V + lane_off_of(ln) + (unsigned)((rb >> 1) * 4096 + (rb & 1) * 8);
         float o[8];
         {
           const u32x4 b0 = lds_u128(bq), b1 = lds_u128(bq + 16);
@@ -305,19 +392,19 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
             hv[j] = a;
             lv[j] = b;
           }
-          // this lane's key is row c of key tile wq; unit g (hi) / 4 + g (lo)
-          *(lds_u128_t)(unsigned long long)(a_K + (unsigned)(wq * 2048)) = hv;
-          *(lds_u128_t)(unsigned long long)(a_K + (unsigned)(wq * 2048 + 1024)) = lv;
+          // this lane's key is row c of key tile rb; unit g (hi) / 4 + g (lo)
+          *(lds_u128_t)(unsigned long long)(aKw) = hv;
+          *(lds_u128_t)(unsigned long long)(aKw + 1024u) = lv;
         }
         // v (normal form): lane c = feature 8 (c / 4) + 4 jv + (c % 4) of the head, registers e = tokens 4 g + e of this wave's 16:
-        // in the 32-key step wq / 2 they are kappa = 8 g + 4 (wq & 1) + e: one 8-byte half of unit g (hi) / 4 + g (lo) of feature row c
+        // in the 32-key step rb / 2 they are kappa = 8 g + 4 (rb & 1) + e: one 8-byte half of unit g (hi) / 4 + g (lo) of feature row c
 #pragma unroll
         for (int jv = 0; jv < 2; ++jv) {
           const float bz = lds_f32(a_B + (unsigned)((2 * D + head * 32 + 8 * (c >> 2) + 4 * jv + (c & 3)) * 4));
           unsigned h0, l0, h1, l1;
           split_pair(__builtin_fmaf(acc[4 + jv][0], oss_v, bz), __builtin_fmaf(acc[4 + jv][1], oss_v, bz), h0, l0);
           split_pair(__builtin_fmaf(acc[4 + jv][2], oss_v, bz), __builtin_fmaf(acc[4 + jv][3], oss_v, bz), h1, l1);
-          const unsigned va = a_V + (unsigned)((wq >> 1) * 4096 + jv * 2048 + (wq & 1) * 8);
+          const unsigned va = aVw + (unsigned)(jv * 2048);
           *(lds_u64_t)(unsigned long long)(va) = u32x2{h0, h1};
           *(lds_u64_t)(unsigned long long)(va + 1024) = u32x2{l0, l1};
         }
@@ -328,60 +415,174 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
 
       if (active) {
         // ================================================================ attention of this wave's 16 queries
-        // S^T tile t = K_t Q^T: lane (query c, g) holds keys 16 t + 4 g + e.  kh qh | kh ql | kl qh
-        f32x4 sacc[8];
+        // LDS bases of this phase as opaque values: every operand address below is one of them + an immediate offset of the instruction.
+        // (Left to itself hipcc forms ~60 distinct addresses once, in front of the loops, and spills them.)
+        const int ln = lane_id();
+        const int c = ln & 15, g = ln >> 4;
+        const unsigned a_R = smem0 + OFF_R + (unsigned)(wq * 2048);
+        const unsigned aKv = smem0 + OFF_K + lane_off_of(ln), aVv = smem0 + OFF_V + lane_off_of(ln),
+                       aEr = smem0 + OFF_E + lane_off_of(ln) + (unsigned)(rb * 2048), aRw = a_R + (unsigned)(ln * 4);
+        // skew gather addresses (see the band below): score (query c, key 16 t + 4 g + e) of S^T tile t takes band row
+        // j = c - (4 g + e) + 15 of the tile pair (t, t - 1): rows 0-15 are tile t (scratch slot t & 1), rows 16-30 tile t - 1 (the other
+        // slot).  A band tile in the scratch: row rho = 4 gg + ee of query cc at float index ee * 64 + gg * 16 + cc (= 4 x lane + 256 ee:
+        // the layout the C/D registers are written with).  ga[e]: the address for EVEN t; odd t: the slots are swapped, address ^ 1024
+        unsigned ga[4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (t < nkt) {
-            const f16x8 kh = lds_f16x8(a_K + (unsigned)(t * 2048)), kl = lds_f16x8(a_K + (unsigned)(t * 2048 + 1024));
-            f32x4 s = mfma16(kh, qh, zero4);
-            s = mfma16(kh, ql, s);
-            sacc[t] = mfma16(kl, qh, s);
+        for (int e = 0; e < 4; ++e) {
+          const int j = c - (4 * g + e) + 15, rho = j & 15;
+          ga[e] = a_R + (unsigned)((j >= 16 ? 1024 : 0) + ((rho & 3) * 64 + (rho >> 2) * 16 + c) * 4);
+        }
+        // (every tile starts as zeros: tiles of a skipped half are never computed and must be zero probabilities for P V)
+        f32x4 sacc[8], oacc[2], oacc2[2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sacc[t] = zero4;
+        oacc[0] = oacc[1] = oacc2[0] = oacc2[1] = zero4;
+        float bvv[8][4];     // gathered band values of the S^T tiles (each lives from its gather to its add, one pipeline step later)
+
+        // ---- S^T tile t = K_t Q^T: lane (query c, g) holds keys 16 t + 4 g + e.  kh qh | kh ql | kl qh; groups of two tiles, the next
+        // group's fragments requested while this one multiplies (two buffers of 16 registers)
+        {
+          auto k_reads = [&](auto T0, f16x8 (&kh)[2], f16x8 (&kl)[2]) __attribute__((always_inline)) {
+            constexpr int t0 = decltype(T0)::value;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              kh[t] = lds_f16x8(aKv + (unsigned)((t0 + t) * 2048));
+              kl[t] = lds_f16x8(aKv + (unsigned)((t0 + t) * 2048 + 1024));
+            }
+          };
+          auto s_mm = [&](auto T0, const f16x8 (&kh)[2], const f16x8 (&kl)[2]) __attribute__((always_inline)) {
+            constexpr int t0 = decltype(T0)::value;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sacc[t0 + t] = mfma16(kh[t], qh, zero4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sacc[t0 + t] = mfma16(kh[t], ql, sacc[t0 + t]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sacc[t0 + t] = mfma16(kl[t], qh, sacc[t0 + t]);
+          };
+          f16x8 kha[2], kla[2], khb[2], klb[2];
+          k_reads(IC<0>{}, kha, kla);
+          FD_SB();
+          k_reads(IC<2>{}, khb, klb);
+          s_mm(IC<0>{}, kha, kla);
+          FD_SB();
+          if (upper) k_reads(IC<4>{}, kha, kla);
+          s_mm(IC<2>{}, khb, klb);
+          FD_SB();
+          if (upper) {
+            k_reads(IC<6>{}, khb, klb);
+            s_mm(IC<4>{}, kha, kla);
+            FD_SB();
+            s_mm(IC<6>{}, khb, klb);
+            FD_SB();
           }
         }
         FD_STAMP(9);
-        // relative_key (HF BertSelfAttention 4.11.3): S[l][r] += q_l . E[l - r + maxpos - 1].  Band tile u, u = -1 .. 7: R^T = E_u Q^T
-        // for the 16 distances l - r = 16 (wq - u) - 15 + rho, rho = 0..15 (LDS table rows 16 (wq - u + 7) + rho: one 16-row group);
-        // S^T tile t needs tiles t (band rows 0-15 of the pair) and t - 1 (rows 16-30).  The tiles go through the wave's scratch
-        // (slot u & 1) in C/D register order and come back skewed, one ds_read_b32 and one fma per score.  eh qh | el qh | eh ql
+        // ---- relative_key (HF BertSelfAttention 4.11.3): S[l][r] += q_l . E[l - r + maxpos - 1].  Band tile u, u = -1 .. 7: R^T = E_u Q^T
+        // for the 16 distances l - r = 16 (rb - u) - 15 + rho, rho = 0..15 (LDS table rows 16 (rb - u + 7) + rho: one 16-row group);
+        // S^T tile t needs tiles t (band rows 0-15 of the pair) and t - 1 (rows 16-30).  eh qh | el qh | eh ql, the tiles of a group side
+        // by side.  The tiles then go through the wave's scratch (slot u & 1) in C/D register order and come back skewed, one
+        // ds_read_b32 per score, in the order write(u) [gather(u)] write(u + 1) gather(u + 1) ...: tile u + 1 replaces tile u - 1, which
+        // gather(u) reads (one wave's LDS operations execute in order; nothing waits for a round trip before the values are added)
+        auto b_reads = [&](auto U0, auto NT, f16x8* eh, f16x8* el) __attribute__((always_inline)) {
+          constexpr int u0 = decltype(U0)::value, nt = decltype(NT)::value;
 #pragma unroll
-        for (int u = -1; u < 8; ++u) {
-          if (u < nkt) {
-            const unsigned ea = a_E + (unsigned)((wq - u + 7) * 2048);
-            const f16x8 eh = lds_f16x8(ea), el = lds_f16x8(ea + 1024);
-            f32x4 r = mfma16(eh, qh, zero4);
-            r = mfma16(el, qh, r);
-            r = mfma16(eh, ql, r);
-            const unsigned wa = a_R + (unsigned)((u & 1) * 1024 + lane * 4);
+          for (int i = 0; i < nt; ++i) {
+            const unsigned ea = aEr + (unsigned)((7 - (u0 + i)) * 2048);
+            eh[i] = lds_f16x8(ea);
+            el[i] = lds_f16x8(ea + 1024);
+          }
+        };
+        auto b_mm = [&](auto NT, const f16x8* eh, const f16x8* el, f32x4* r) __attribute__((always_inline)) {
+          constexpr int nt = decltype(NT)::value;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) *(lds_f32_t)(unsigned long long)(wa + (unsigned)(e * 256)) = r[e];
+          for (int i = 0; i < nt; ++i) r[i] = mfma16(eh[i], qh, zero4);
+#pragma unroll
+          for (int i = 0; i < nt; ++i) r[i] = mfma16(el[i], qh, r[i]);
+#pragma unroll
+          for (int i = 0; i < nt; ++i) r[i] = mfma16(eh[i], ql, r[i]);
+        };
+        auto b_skew = [&](auto U0, auto NT, const f32x4* r) __attribute__((always_inline)) {
+          constexpr int u0 = decltype(U0)::value, nt = decltype(NT)::value;
+#pragma unroll
+          for (int i = 0; i < nt; ++i) {
+            const int u = u0 + i;
+            const unsigned wa = aRw + (unsigned)((u & 1) * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(lds_f32_t)(unsigned long long)(wa + (unsigned)(e * 256)) = r[i][e];
             if (u >= 0) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float bv = lds_f32((u & 1) ? (gad[e] ^ 1024u) : gad[e]);
-                sacc[u][e] = __builtin_fmaf(bv, p.r_scale, sacc[u][e]);
-              }
+              for (int e = 0; e < 4; ++e) bvv[u < 0 ? 0 : u][e] = lds_f32((u & 1) ? (ga[e] ^ 1024u) : ga[e]);
             }
           }
+        };
+        auto b_add = [&](auto T0, auto NT) __attribute__((always_inline)) {
+          constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value;
+#pragma unroll
+          for (int t = t0; t < t0 + nt; ++t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc[t][e] = __builtin_fmaf(bvv[t][e], p.r_scale, sacc[t][e]);
+          }
+        };
+        {
+          // groups: (-1, 0) (1, 2) (3) | (4, 5) (6, 7); a group's fragments are requested while the group before multiplies, its tiles
+          // pass the scratch while the next group multiplies, its gathered values are added a step later
+          f16x8 eha[2], ela[2], ehb[2], elb[2];
+          f32x4 ra[2], rbb[2];
+          b_reads(IC<-1>{}, IC<2>{}, eha, ela);
+          FD_SB();
+          b_reads(IC<1>{}, IC<2>{}, ehb, elb);
+          b_mm(IC<2>{}, eha, ela, ra);
+          FD_SB();
+          b_reads(IC<3>{}, IC<1>{}, eha, ela);
+          b_mm(IC<2>{}, ehb, elb, rbb);
+          b_skew(IC<-1>{}, IC<2>{}, ra);
+          FD_SB();
+          if (upper) b_reads(IC<4>{}, IC<2>{}, ehb, elb);
+          b_mm(IC<1>{}, eha, ela, ra);
+          b_skew(IC<1>{}, IC<2>{}, rbb);
+          b_add(IC<0>{}, IC<1>{});
+          FD_SB();
+          b_skew(IC<3>{}, IC<1>{}, ra);
+          b_add(IC<1>{}, IC<2>{});
+          if (upper) {
+            b_reads(IC<6>{}, IC<2>{}, eha, ela);
+            b_mm(IC<2>{}, ehb, elb, rbb);
+          }
+          FD_SB();
+          b_add(IC<3>{}, IC<1>{});
+          if (upper) {
+            b_mm(IC<2>{}, eha, ela, ra);
+            b_skew(IC<4>{}, IC<2>{}, rbb);
+            FD_SB();
+            b_skew(IC<6>{}, IC<2>{}, ra);
+            b_add(IC<4>{}, IC<2>{});
+            FD_SB();
+            b_add(IC<6>{}, IC<2>{});
+          }
+          FD_SB();
         }
         FD_STAMP(10);
-        // key mask (this lane + lanes c + 16 g' hold one query's scores) and the row maximum
+        // ---- key mask (this lane + lanes c + 16 g' hold one query's scores), the row maximum, the exponentials, the row sum
         float mt = -INFINITY;
+        {
+          int g4 = 4 * g;
+          asm volatile("" : "+v"(g4));
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (t < nkt) {
-            if (len < 16 * (t + 1)) {
+          for (int t = 0; t < 8; ++t) {
+            if (t < 4 || upper) {
+              if (len < 16 * (t + 1)) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int key = 16 * t + 4 * g + e;
-                float sc = sacc[t][e];
-                if (key >= len) sc += mask_raw;  // (1 - mask) * -10000   (modelling.py:452)
-                if (key >= Lb) sc = -INFINITY;   // not a key at all (rows that do not exist)
-                sacc[t][e] = sc;
+                for (int e = 0; e < 4; ++e) {
+                  // key = 16 t + 4 g + e, compared as 4 g against a scalar (32 loop-invariant key indices would be hoisted and spilled)
+                  float sc = sacc[t][e];
+                  if (g4 >= len - 16 * t - e) sc += mask_raw;  // key >= len: (1 - mask) * -10000   (modelling.py:452)
+                  if (g4 >= Lb - 16 * t - e) sc = -INFINITY;   // key >= Lb: not a key at all (rows that do not exist)
+                  sacc[t][e] = sc;
+                }
               }
-            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mt = fmaxf(mt, sacc[t][e]);
+              for (int e = 0; e < 4; ++e) mt = fmaxf(mt, sacc[t][e]);
+            }
           }
         }
         mt = quad_max(mt);
@@ -390,47 +591,70 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          if (t < nkt) {
+          if (t < 4 || upper) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][e], s_scale, nm));
               sacc[t][e] = pe;
               psum += pe;
             }
-          } else {
-            sacc[t] = zero4;
           }
         }
         const float l_run = quad_sum(psum);  // carries the factor PS
         FD_STAMP(11);
-        // O^T = V^T P^T over 32-key steps: kappa = 8 g + 4 p + e <-> key 16 (2 s4 + p) + 4 g + e.  vh ph | vl ph | vh pl
-        f32x4 oacc[2] = {zero4, zero4};
+        // ---- O^T = V^T P^T over 32-key steps: kappa = 8 g + 4 p + e <-> key 16 (2 s4 + p) + 4 g + e.  vh ph | vl ph | vh pl; even steps
+        // accumulate into oacc, odd ones into oacc2 (four independent MFMA chains per round of two steps), added at the end
+        auto pv_round = [&](auto S0) __attribute__((always_inline)) {  // steps s0, s0 + 1
+          constexpr int s0 = decltype(S0)::value;
+          f16x8 vh[2][2], vl[2][2], ph[2], pl[2];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          if (2 * s4 < nkt) {
+          for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int jv = 0; jv < 2; ++jv) {
+              const unsigned va = aVv + (unsigned)((s0 + k) * 4096 + jv * 2048);
+              vh[k][jv] = lds_f16x8(va);
+              vl[k][jv] = lds_f16x8(va + 1024);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
             u32x4 phu, plu;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               unsigned a, b;
-              split_pair(sacc[2 * s4 + (j >> 1)][2 * (j & 1)], sacc[2 * s4 + (j >> 1)][2 * (j & 1) + 1], a, b);
+              split_pair(sacc[2 * (s0 + k) + (j >> 1)][2 * (j & 1)], sacc[2 * (s0 + k) + (j >> 1)][2 * (j & 1) + 1], a, b);
               phu[j] = a;
               plu[j] = b;
             }
-            const f16x8 ph = __builtin_bit_cast(f16x8, phu), pl = __builtin_bit_cast(f16x8, plu);
-#pragma unroll
-            for (int jv = 0; jv < 2; ++jv) {
-              const unsigned va = a_V + (unsigned)(s4 * 4096 + jv * 2048);
-              const f16x8 vh = lds_f16x8(va), vl = lds_f16x8(va + 1024);
-              f32x4 o2 = mfma16(vh, ph, oacc[jv]);
-              o2 = mfma16(vl, ph, o2);
-              oacc[jv] = mfma16(vh, pl, o2);
-            }
+            ph[k] = __builtin_bit_cast(f16x8, phu);
+            pl[k] = __builtin_bit_cast(f16x8, plu);
           }
-        }
+          FD_SB();
+#pragma unroll
+          for (int jv = 0; jv < 2; ++jv) {
+            oacc[jv] = mfma16(vh[0][jv], ph[0], oacc[jv]);
+            oacc2[jv] = mfma16(vh[1][jv], ph[1], oacc2[jv]);
+          }
+#pragma unroll
+          for (int jv = 0; jv < 2; ++jv) {
+            oacc[jv] = mfma16(vl[0][jv], ph[0], oacc[jv]);
+            oacc2[jv] = mfma16(vl[1][jv], ph[1], oacc2[jv]);
+          }
+#pragma unroll
+          for (int jv = 0; jv < 2; ++jv) {
+            oacc[jv] = mfma16(vh[0][jv], pl[0], oacc[jv]);
+            oacc2[jv] = mfma16(vh[1][jv], pl[1], oacc2[jv]);
+          }
+          FD_SB();
+        };
+        pv_round(IC<0>{});
+        if (upper) pv_round(IC<2>{});
         FD_STAMP(12);
-        // ctx[token row][head block] = O^T / l_run at the ctx image's scale: lane (query c, g) holds features 8 g + 4 jv + e = unit g
+        // ---- ctx[token row][head block] = O^T / l_run at the ctx image's scale: lane (query c, g) holds features 8 g + 4 jv + e = unit g
         {
           const float onorm = p.ctx_scale / (p.v_scale * l_run);
+          oacc[0] += oacc2[0];
+          oacc[1] += oacc2[1];
           u32x4 hv, lv;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -439,7 +663,7 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
             hv[j] = a;
             lv[j] = b;
           }
-          const int l = 16 * wq + c, row = row0 + l;
+          const int l = 16 * rb + c, row = row0 + l;
           unsigned voff = (unsigned)((((row >> 5) * H * 8 + g) * 32 + (row & 31)) * 16);
           voff = l < nrows ? voff : 0xFFFFFF00u;  // rows that are no rows of the sequence: dropped by the range check
           __builtin_amdgcn_raw_buffer_store_b128(hv, rsc, (int)voff, head * 4096, 0);
@@ -459,9 +683,16 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
     if (next_seq >= p.B) break;
     seq = next_seq;
     sload4(p.seq_row0, seq, p.seq_row0, seq + 1, p.nrow, seq, p.lens, seq, row0, row1, Lb, len);
+    // the next sequence's hidden state, waited for at once (2-3 k cycles per sequence of ~170 k).  Requested inside the head loop --
+    // behind the last projection, so that it lands under the last head's attention -- the loads are loop-carried for hipcc's wait
+    // counter model, and with the two groups requesting their weight pieces at different places of a stage that model gives up
+    // counting: it put vmcnt(2) .. vmcnt(0) in front of the MFMAs of EVERY head's last stage, which drains the weight stream.
+    load_h(row0);
+    FD_WAIT_VM(0);
   }
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 #undef FD_STAMP
+#undef FD_SB
 }
 
 static int n_cu_of(int dev) {

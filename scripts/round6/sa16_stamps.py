@@ -37,9 +37,9 @@ for w in (0, 4, 7):
     s = a[w]
     used = [i for i in range(32) if s[i, 0]]
     print(f"wave {w}: {len(used)} head iterations; ticks per piece: " + " ".join(f"{v:>5s}" for v in names) + " |   head")
-    for i in used[:26]:
+    for i in used[:14]:
         r = s[i]
         d = [int(r[k + 1] - r[k]) if r[k + 1] and r[k] else 0 for k in range(13)]
         print(f"  it {i:2d}: " + " " * 22 + " ".join(f"{v:5d}" for v in d) + f" | {int(r[13] - r[0]):6d}")
-    m = np.array([[int(s[i][k + 1] - s[i][k]) for k in range(13)] for i in used[1:24]])
+    m = np.array([[int(s[i][k + 1] - s[i][k]) for k in range(13)] for i in used[1:11]])
     print("  mean:  " + " " * 22 + " ".join(f"{v:5.0f}" for v in m.mean(axis=0)) + f" | {m.sum(axis=1).mean():6.0f}")
