@@ -17,7 +17,7 @@ Inputs (x_T, lengths, weights, tables) are resident in HBM before the timed
 region starts.  Nothing is skipped or cached between passes.
 
 The JSON line also carries
-  roofline      the dominant kernel (the fused q|k|v projection + attention kernel; the q|k|v GEMM where that does not run):
+  roofline      the dominant kernel (the fused q|k|v projection + attention kernel, seq_attn16.hip; the q|k|v GEMM where that does not run):
                 algorithmic FLOPs per launch /
                 average launch duration measured live with hipEvents inside the timed
                 region (every 100th timestep is launched eagerly with an event pair per
@@ -313,11 +313,15 @@ def main():
     dom = kernels.get(dom_name)
     pinfo_key = model.precision  # (the exact-fp32 pass below switches the model)
     pinfo = PRECISION_INFO[pinfo_key]
-    dom_kernel = ("sa::seq_attn_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, fp16 hi/lo "
-                  "split, 3x v_mfma_f32_32x32x16_f16 per product)") if dom_name == "qkv_attention_fused" else pinfo["kernel"]
+    legacy_fused = os.environ.get("FDMI_FUSE_ATTN") == "2"
+    dom_kernel = pinfo["kernel"]
+    if dom_name == "qkv_attention_fused":
+        dom_kernel = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_32x32x16_f16 per product)" if legacy_fused else
+                      "s16::seq_attn16_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, 16-row waves, "
+                      "two per SIMD, fp16 hi/lo split, 3x v_mfma_f32_16x16x32_f16 per product)")
     traffic, traffic_note = None, "not measured (--no-traffic, N > 1 or another shape)"
     if world == 1 and not args.no_traffic and (B, L) == (512, 128) and dom:
-        traffic, traffic_note = measure_traffic("seq_attn_kernel" if dom_name == "qkv_attention_fused" else
+        traffic, traffic_note = measure_traffic("seq_attn" if dom_name == "qkv_attention_fused" else
                                                 ("gemm_img_kernel<5" if model.precision == "f16x3" else "gemm_f32_kernel"), args)
     roofline = None
     if dom:

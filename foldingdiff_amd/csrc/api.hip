@@ -726,10 +726,12 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     // waves, two per SIMD; any L <= 128, padded or packed rows), 2 = seq_attn.hip (round 5: 32-row waves, 96 < L <= 128), 0 = never
     static const int fuse_attn_env = [] { const char* e = getenv("FDMI_FUSE_ATTN"); return e ? atoi(e) : -1; }();
     const int fuse_attn = m->fuse_attn >= 0 ? m->fuse_attn : fuse_attn_env;
-    // auto: when the batch fills whole rounds of the CUs (one workgroup = one sequence at a time: 512 sequences on 256 CUs are two full
-    // rounds, 300 would leave the second round four-fifths empty and 8 sequences would run on 8 CUs)
-    bool fused_auto = false;
-    {
+    // auto: padded rows of 97..128 positions when the batch fills whole rounds of the CUs (one workgroup = one sequence at a time: 512
+    // sequences on 256 CUs are two full rounds, 300 would leave the second round four-fifths empty and 8 sequences would run on 8 CUs).
+    // Measured (profiles/r06_seq_attn16_notes.log): packed rows of BASELINE C3's first chunk (B 512, lengths 50..101) are a tie with
+    // the two-kernel path (5.29 against 5.25 ms per step), its second chunk (B 268) and batches of a few sequences lose.
+    bool fused_auto = !m->varlen && L > 96;
+    if (fused_auto) {
       const int ncu = gemm_img_grid(1 << 30, 384);  // (= the CU count, rounded down to whole XCDs)
       const int rounds = (B + ncu - 1) / ncu;
       fused_auto = (double)B >= 0.94 * (double)rounds * ncu;

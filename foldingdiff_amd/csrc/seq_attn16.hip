@@ -115,7 +115,7 @@ __device__ __forceinline__ void static_for(F&& f) {
                         // 4 = no projection MFMAs
 #endif
 #ifndef FDMI_S16_PRIO
-#define FDMI_S16_PRIO 0  // > 0: s_setprio of a wave while it attends (its projecting partner on the SIMD runs at 0)
+#define FDMI_S16_PRIO 2  // > 0: s_setprio of a wave around the twelve hi-plane MFMAs of a projection step (0: off; +1.2 % same box)
 #endif
 
 __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
@@ -226,130 +226,156 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 32 && lane == 0) stp[slot * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define FD_SB() __builtin_amdgcn_sched_barrier(0)
 
-  int seq = blockIdx.x;
-  if (seq >= p.B) return;
-  int row0, row1, Lb, len;  // the sequence's first row, the next sequence's, rows that exist (keys), unmasked keys
-  sload4(p.seq_row0, seq, p.seq_row0, seq + 1, p.nrow, seq, p.lens, seq, row0, row1, Lb, len);
-  load_h(row0);
+  if ((int)blockIdx.x >= p.B) return;
+  const int nseq = (p.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int N = nseq * H;  // items (= heads of sequences) of this workgroup
+  // An ITEM is projected in two parts: its EARLY stages (0 .. NE-1) inside the previous item's attention region, its LATE stages
+  // (NE .. NS-1) by all waves in step.  The region is where the two waves of a SIMD part ways: group 0 runs the attention of item i
+  // and then the early stages of item i + 1, group 1 the other way round -- the attention's LDS round trips, skew and softmax
+  // (VALU / latency bound, few MFMAs) sit beside the partner's projection steps (MFMA bound) instead of beside the partner's
+  // softmax.  In step (everything else) both waves of a SIMD want the same unit at the same time.
+  constexpr int NE = NS == 6 ? 2 : 1;
+  // sequence of the item whose late stages / epilogue / attention run (a_*) and of the item after it (n_*: early stages)
+  int n_seq = blockIdx.x, n_head = 0, n_row0, n_row1, n_Lb, n_len;
+  sload4(p.seq_row0, n_seq, p.seq_row0, n_seq + 1, p.nrow, n_seq, p.lens, n_seq, n_row0, n_row1, n_Lb, n_len);
+  int a_head = 0, a_row0 = 0, a_row1 = 0, a_Lb = 0, a_len = 0;
+  load_h(n_row0);
   issue_w();
   issue_w();
-  FD_WAIT_VM(3);  // stage 0 (and the hidden state, requested before it) landed
+  issue_w();
   const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.ctx, 0, 0xFFFFFF00u, 0x00020000);
-  int pos = 0;  // ring slot of the stage being computed (byte offset)
+  int pos = 0;  // ring slot (byte offset) of stage 0 of the item whose stages are read
+  f32x4 acc[6];  // q tile 0, 1 | k tile 0, 1 (swapped form: lane = token) | v tile 0, 1 (normal form: lane = feature)
 
-  for (;;) {
-    const int nrows = row1 - row0;
+  // ---- projection steps [KS0, KS1) of the item whose first stage sits in ring slot `pos`: a software pipeline over k32 steps -- two
+  // fragment buffers of six tiles (48 registers) alternate over the planes hi(ks) lo(ks) hi(ks + 1) ...: while a plane multiplies
+  // (hi: 12 MFMAs, lo: 6) the next one is requested into the other buffer, across stage boundaries too.  TOPS: the steps of this
+  // range carry the stage tops of the late stages: the barrier that publishes stage j = steps 2 j, 2 j + 1 sits inside step 2 j - 1,
+  // behind that step's lo-plane reads (the last reads of stage j - 1, whose ring slot the request at that top overwrites) and in
+  // front of the reads of hi(2 j).  The two waves of a SIMD have the top at different places: group 0 in front of the step's twelve
+  // hi-plane MFMAs, group 1 behind them (one wave's requests, ~210 cycles, beside the other's MFMAs).
+  // Stage-top waits: vmcnt retires in issue order; when stage G is published the only younger requests are those of stage G + 1
+  // (d_model 192, three stages per head: none).
+  auto proj_steps = [&](auto KS0, auto KS1, auto TOPS, bool act) __attribute__((always_inline)) {
+    constexpr int ks0 = decltype(KS0)::value, ks1 = decltype(KS1)::value;
+    constexpr bool tops = decltype(TOPS)::value;
+    auto stage_top = [&]() __attribute__((always_inline)) {
+      if constexpr (NS == 6) FD_WAIT_VM(3);
+      else FD_WAIT_VM(0);
+      barrier_keep_vm();
+      issue_w();
+    };
+    f16x8 fx[6], fy[6];
+    unsigned a_W = smem0 + OFF_W + lane_off_of(lane_id());
+    auto plane_reads = [&](auto KS, auto LO, f16x8 (&f)[6]) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value, lo = decltype(LO)::value;
+      int off = pos + (ks >> 1) * STAGE;
+      off = off >= NST * STAGE ? off - NST * STAGE : off;
+      unsigned sb = a_W + (unsigned)(off + (ks & 1) * KS_BYTES + lo * 1024);
+      asm volatile("" : "+v"(sb));
+#pragma unroll
+      for (int t = 0; t < 6; ++t) f[t] = lds_f16x8(sb + (unsigned)(t * 2048));
+    };
+    // per accumulator: wh hh | wh hl | wl hh (gemm_img.hip's order); consecutive MFMAs never share an accumulator
+    auto mm_hh = [&](auto KS, const f16x8 (&fh)[6]) __attribute__((always_inline)) {
+      constexpr int kt = decltype(KS)::value;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(fh[t], hh[kt], acc[t]);
+#pragma unroll
+      for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], fh[t], acc[t]);
+    };
+    auto mm_hl = [&](auto KS, const f16x8 (&fh)[6]) __attribute__((always_inline)) {
+      constexpr int kt = decltype(KS)::value;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(fh[t], hl[kt], acc[t]);
+#pragma unroll
+      for (int t = 4; t < 6; ++t) acc[t] = mfma16(hl[kt], fh[t], acc[t]);
+    };
+    auto mm_lh = [&](auto KS, const f16x8 (&fl)[6]) __attribute__((always_inline)) {
+      constexpr int kt = decltype(KS)::value;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(fl[t], hh[kt], acc[t]);
+#pragma unroll
+      for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], fl[t], acc[t]);
+    };
+    // (activity tests around the pieces of a step make hipcc spill: a wave without rows takes a path of its own, stage tops only)
+    if (act) {
+      plane_reads(KS0, IC<0>{}, fx);
+      FD_SB();
+      static_for<ks0, ks1>([&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        constexpr bool top = tops && (ks & 1) == 1 && ks + 1 < ks1;  // publishes the stage of steps ks + 1, ks + 2
+        plane_reads(KS, IC<1>{}, fy);
+        FD_SB();
+        if constexpr (top) {
+          if (grp == 0) stage_top();
+        }
+#if FDMI_S16_PRIO
+        __builtin_amdgcn_s_setprio(FDMI_S16_PRIO);  // MFMAs of ONE wave back to back: alternating between the SIMD's two waves they issue slower
+#endif
+        mm_hh(KS, fx);
+        mm_hl(KS, fx);
+#if FDMI_S16_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        FD_SB();
+        if constexpr (top) {
+          if (grp != 0) stage_top();
+        }
+        if constexpr (ks + 1 < ks1) plane_reads(IC<ks + 1>{}, IC<0>{}, fx);
+        FD_SB();
+        mm_lh(KS, fy);
+        FD_SB();
+      });
+    } else if constexpr (tops) {
+      static_for<ks0, ks1>([&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        if constexpr ((ks & 1) == 1 && ks + 1 < ks1) stage_top();
+      });
+    }
+  };
+
+  // ---- prologue: the early stages of item 0 by every wave, then the first "closing" barrier (see the loop)
+  FD_WAIT_VM(3);  // the hidden state and stages 0, 1 landed (requested in this order; stage 2 may still be in flight)
+  barrier_keep_vm();
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc[t] = zero4;
+  bool n_act = 16 * rb < n_Lb;  // this wave owns rows of the item's sequence (wave-uniform)
+  proj_steps(IC<0>{}, IC<2 * NE>{}, IC<0>{}, n_act);
+  FD_WAIT_VM(0);
+  barrier_keep_vm();  // stage NE landed for every wave; every wave is done with the early stages: their ring slots are free
+#pragma unroll
+  for (int k = 0; k < NE; ++k) issue_w();
+
+  for (int item = 0; item < N; ++item) {
+    // ---- the item's late stages, all waves in step
+    FD_STAMP(0);
+    const bool act = n_act;
+    proj_steps(IC<2 * NE>{}, IC<NKT>{}, IC<1>{}, act);
+    FD_STAMP(1);
+    // this item becomes the attended one; the next item (if any) is the one whose early stages run in the region
+    a_head = n_head; a_row0 = n_row0; a_row1 = n_row1; a_Lb = n_Lb; a_len = n_len;
+    const bool has_next = item + 1 < N;
+    if (has_next) {
+      if (n_head == H - 1) {
+        // the hidden state is dead: the next sequence's replaces it under the epilogue (waited for in front of the K / V barrier)
+        n_head = 0;
+        n_seq += (int)gridDim.x;
+        sload4(p.seq_row0, n_seq, p.seq_row0, n_seq + 1, p.nrow, n_seq, p.lens, n_seq, n_row0, n_row1, n_Lb, n_len);
+        load_h(n_row0);
+        n_act = 16 * rb < n_Lb;
+      } else {
+        ++n_head;
+      }
+    }
+    const int head = a_head, row0 = a_row0, Lb = a_Lb, len = a_len;
+    const int nrows = a_row1 - a_row0;
     const int nkt = (Lb + 15) >> 4;         // key tiles that hold a key at all
     const bool upper = nkt > 4;             // the sequence has keys beyond 64: work is skipped in halves of the key range
-    const bool active = 16 * rb < Lb;       // this wave owns rows of the sequence (wave-uniform)
-    const int next_seq = seq + (int)gridDim.x;
-    for (int head = 0; head < H; ++head) {
-      // ================================================================ projection of head `head`
-      FD_STAMP(0);
-      f32x4 acc[6];  // q tile 0, 1 | k tile 0, 1 (swapped form: lane = token) | v tile 0, 1 (normal form: lane = feature)
-#pragma unroll
-      for (int t = 0; t < 6; ++t) acc[t] = zero4;
-      // The projection is a software pipeline over the head's NKT k32 steps: the twelve fragments of step ks + 1 are requested while
-      // step ks multiplies (two fragment buffers of 48 registers), across stage boundaries too -- the barrier that publishes stage j
-      // (= steps 2 j, 2 j + 1) sits at the START of step 2 j - 1, when every fragment of stage j - 1 is already in registers: that
-      // stage's ring slot is free for stage j + 2 right there, and the matrix instructions never wait for a barrier + LDS round trip
-      // except at the head's first step.  (gemm_img.hip hides its k-tile barrier the same way.)
-      // Stage tops: this stage landed (its three pieces of this wave; every wave says so at the barrier).  vmcnt retires in issue
-      // order: at most the pieces of the stage after this one may be outstanding -- and, at the first two tops of a head, the two ctx
-      // stores of the head before, which are younger than this stage's pieces.
-      // Two fragment buffers of six tiles (48 registers) alternate over the planes hi(0) lo(0) hi(1) lo(1) ...: while a plane multiplies
-      // (hi: 12 MFMAs, lo: 6) the next one is requested into the other buffer.  (72 or 96 registers of fragments made hipcc keep part
-      // of the hidden state in scratch, reloaded behind vmcnt(0): that drains the weight stream.)
-      f16x8 fx[6], fy[6];
-      unsigned a_W = smem0 + OFF_W + lane_off_of(lane_id());
-      // A stage top = this wave's pieces of the stage landed (vmcnt retires in issue order: at most the pieces of the stage after
-      // this one may be outstanding -- and, at the first two tops of a head, the two ctx stores of the head before, which are younger
-      // than this stage's pieces), workgroup barrier (they landed for every wave; every wave has READ the last fragment of the stage
-      // two before the one that is requested next, whose ring slot that request overwrites), request of the stage after next.
-      // The barrier that publishes stage j = steps 2 j, 2 j + 1 sits inside step 2 j - 1: behind that step's lo-plane reads (the
-      // last reads of stage j - 1) and in front of the reads of hi(2 j).
-      auto stage_wait_barrier = [&](auto ST) __attribute__((always_inline)) {
-        constexpr int st = decltype(ST)::value;
-        if (st < 2) FD_WAIT_VM(5);
-        else FD_WAIT_VM(3);
-        barrier_keep_vm();
-      };
-      auto plane_reads = [&](auto KS, auto LO, f16x8 (&f)[6]) __attribute__((always_inline)) {
-        constexpr int ks = decltype(KS)::value, lo = decltype(LO)::value;
-        // ring slot of the stage that holds step ks: `pos` is the slot of the head's first stage
-        int off = pos + (ks >> 1) * STAGE;
-        off = off >= NST * STAGE ? off - NST * STAGE : off;
-        unsigned sb = a_W + (unsigned)(off + (ks & 1) * KS_BYTES + lo * 1024);
-        asm volatile("" : "+v"(sb));
-#pragma unroll
-        for (int t = 0; t < 6; ++t) f[t] = lds_f16x8(sb + (unsigned)(t * 2048));
-      };
-      // per accumulator: wh hh | wh hl | wl hh (gemm_img.hip's order); consecutive MFMAs never share an accumulator
-      auto mm_hh = [&](auto KS, const f16x8 (&fh)[6]) __attribute__((always_inline)) {
-        constexpr int kt = decltype(KS)::value;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fh[t], hh[kt], acc[t]);
-#pragma unroll
-        for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], fh[t], acc[t]);
-      };
-      auto mm_hl = [&](auto KS, const f16x8 (&fh)[6]) __attribute__((always_inline)) {
-        constexpr int kt = decltype(KS)::value;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fh[t], hl[kt], acc[t]);
-#pragma unroll
-        for (int t = 4; t < 6; ++t) acc[t] = mfma16(hl[kt], fh[t], acc[t]);
-      };
-      auto mm_lh = [&](auto KS, const f16x8 (&fl)[6]) __attribute__((always_inline)) {
-        constexpr int kt = decltype(KS)::value;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fl[t], hh[kt], acc[t]);
-#pragma unroll
-        for (int t = 4; t < 6; ++t) acc[t] = mfma16(hh[kt], fl[t], acc[t]);
-      };
-      // The head's first stage: published by a barrier of its own, its first hi plane read behind it (the one LDS round trip per head
-      // that the matrix pipe waits for)
-      stage_wait_barrier(IC<0>{});
-      issue_w();
-      // The two waves of a SIMD run the same instruction sequence; only the stage top (barrier + the three LDS-DMA requests, ~300
-      // cycles without a matrix instruction) sits at different places: group 0 has it in front of the step's twelve hi-plane MFMAs,
-      // group 1 behind them -- in the steady state group 1 runs twelve MFMAs ahead, and one wave's read bursts and requests sit beside
-      // the other's MFMAs instead of beside its own.  (Two different step sequences, branched per head or per step, made hipcc spill;
-      // so do activity tests around the pieces of a step: a wave without rows takes a path of its own, stage tops only.)
-      if (active) {
-        plane_reads(IC<0>{}, IC<0>{}, fx);
-        FD_SB();
-        static_for<0, NKT>([&](auto KS) __attribute__((always_inline)) {
-          constexpr int ks = decltype(KS)::value;
-          constexpr bool top = (ks & 1) == 1 && ks + 1 < NKT;  // this step carries the barrier that publishes the stage of steps ks + 1, ks + 2
-          plane_reads(KS, IC<1>{}, fy);
-          FD_SB();
-          if constexpr (top) {
-            if (grp == 0) { stage_wait_barrier(IC<(ks + 1) / 2>{}); issue_w(); }
-          }
-          mm_hh(KS, fx);
-          mm_hl(KS, fx);
-          FD_SB();
-          if constexpr (top) {
-            if (grp != 0) { stage_wait_barrier(IC<(ks + 1) / 2>{}); issue_w(); }
-          }
-          if constexpr (ks + 1 < NKT) plane_reads(IC<ks + 1>{}, IC<0>{}, fx);
-          FD_SB();
-          mm_lh(KS, fy);
-          FD_SB();
-          if constexpr ((ks & 1) == 1) FD_STAMP(1 + ks / 2);
-        });
-      } else {
-        static_for<1, NS>([&](auto ST) __attribute__((always_inline)) {
-          stage_wait_barrier(ST);
-          issue_w();
-        });
-      }
-      pos = pos + NS * STAGE;
-      pos = pos >= 2 * NST * STAGE ? pos - 2 * NST * STAGE : (pos >= NST * STAGE ? pos - NST * STAGE : pos);
-
-      f16x8 qh, ql;  // Q^T operand of the head: this lane's token, features 8 g .. 8 g + 7
-      qh = ql = __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
-      if (active) {
+    const bool active = act;
+    f16x8 qh, ql;  // Q^T operand of the head: this lane's token, features 8 g .. 8 g + 7
+    qh = ql = __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
+    if (active) {
         // ================================================================ epilogue: q_h -> registers, k_h -> LDS, v_h -> LDS
         // (same arithmetic as gemm_img.hip's q | k and v^T epilogues: fma(acc, os sc, b sc), then the split)
         const int ln = lane_id();
@@ -408,11 +434,18 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
           *(lds_u64_t)(unsigned long long)(va) = u32x2{h0, h1};
           *(lds_u64_t)(unsigned long long)(va + 1024) = u32x2{l0, l1};
         }
-      }
-      FD_STAMP(7);
-      barrier_keep_vm();  // K and V^T of the head are complete
-      FD_STAMP(8);
-
+    }
+    FD_STAMP(2);
+    // K and V^T of the item are complete; the early stages of the next item (requested at the last two stage tops) and, at a
+    // sequence's end, the next hidden state landed: this wave's every vector-memory operation is behind it
+    FD_WAIT_VM(0);
+    barrier_keep_vm();
+    issue_w();  // (the ring slot of the item's last stage is free: the next item's stage NE)
+    pos = pos + NS * STAGE;
+    pos = pos >= 2 * NST * STAGE ? pos - 2 * NST * STAGE : (pos >= NST * STAGE ? pos - NST * STAGE : pos);
+    FD_STAMP(3);
+    // ================================================================ the region
+    auto attention = [&]() __attribute__((always_inline)) {
       if (active) {
         // ================================================================ attention of this wave's 16 queries
         // LDS bases of this phase as opaque values: every operand address below is one of them + an immediate offset of the instruction.
@@ -653,8 +686,11 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
         // ---- ctx[token row][head block] = O^T / l_run at the ctx image's scale: lane (query c, g) holds features 8 g + 4 jv + e = unit g
         {
           const float onorm = p.ctx_scale / (p.v_scale * l_run);
-          oacc[0] += oacc2[0];
-          oacc[1] += oacc2[1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {  // (element by element: a vector add becomes v_pk_add_f32, which serializes with the partner's MFMAs)
+            oacc[0][e] = oacc[0][e] + oacc2[0][e];
+            oacc[1][e] = oacc[1][e] + oacc2[1][e];
+          }
           u32x4 hv, lv;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -671,24 +707,36 @@ __global__ __launch_bounds__(64 * NW) void seq_attn16_kernel(SeqAttnArgs p) {
           store_guard(hv, lv);
         }
       } else {
-        // a wave without rows issues the same number of vector-memory operations per head (the stage-top waits count them)
+        // a wave without rows issues the same number of vector-memory operations per item (the waits count them)
         u32x4 z = {0u, 0u, 0u, 0u};
         __builtin_amdgcn_raw_buffer_store_b128(z, rsc, (int)0xFFFFFF00u, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(z, rsc, (int)0xFFFFFF00u, 0, 0);
         store_guard(z, z);
       }
-      FD_STAMP(13);
-      ++slot;
+    };
+    auto early = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) acc[t] = zero4;
+      if (has_next) proj_steps(IC<0>{}, IC<2 * NE>{}, IC<0>{}, n_act);
+    };
+    if (grp == 0) {
+      attention();
+      FD_STAMP(4);
+      early();
+    } else {
+      early();
+      FD_STAMP(4);
+      attention();
     }
-    if (next_seq >= p.B) break;
-    seq = next_seq;
-    sload4(p.seq_row0, seq, p.seq_row0, seq + 1, p.nrow, seq, p.lens, seq, row0, row1, Lb, len);
-    // the next sequence's hidden state, waited for at once (2-3 k cycles per sequence of ~170 k).  Requested inside the head loop --
-    // behind the last projection, so that it lands under the last head's attention -- the loads are loop-carried for hipcc's wait
-    // counter model, and with the two groups requesting their weight pieces at different places of a stage that model gives up
-    // counting: it put vmcnt(2) .. vmcnt(0) in front of the MFMAs of EVERY head's last stage, which drains the weight stream.
-    load_h(row0);
-    FD_WAIT_VM(0);
+    FD_STAMP(5);
+    // the next item's stage NE landed (requested at the K / V barrier; only this wave's two ctx stores are younger); every wave is
+    // done with the early stages: their ring slots take the stages after it
+    FD_WAIT_VM(2);
+    barrier_keep_vm();
+#pragma unroll
+    for (int k = 0; k < NE; ++k) issue_w();
+    FD_STAMP(6);
+    ++slot;
   }
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 #undef FD_STAMP

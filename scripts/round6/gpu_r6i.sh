@@ -1,7 +1,7 @@
 #!/bin/bash
-cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r6l
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r6m
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-O=gpurun_out/r6l
+O=gpurun_out/r6m
 CASES=0,1,2,3,5,7 timeout 900 python scripts/round6/sa16_check.py 2>&1 | tail -14 | tee $O/sa16_check.log
 for rep in 1 2; do
 for fa in 1 2; do

@@ -32,14 +32,23 @@ n = n0 + 4 * 64 * 16 + 16384
 buf = np.zeros(n, dtype=np.uint64)
 _binding.check(lib.fd_debug_read(h, b"stamps", buf.ctypes.data_as(C.c_void_p), 2 * n))
 a = buf[n0:n0 + 8 * 32 * 16].reshape(8, 32, 16).astype(np.int64)
-names = ["st0", "st1", "st2", "st3", "st4", "st5", "epi", "bar", "S^T", "band", "smax", "PV", "store"]
-for w in (0, 4, 7):
+print("per item: late stages (all waves in step) | epilogue | K/V barrier | region first half | region second half | closing barrier")
+print("          region: group 0 (waves 0-3) = attention then the next item's early stages, group 1 the other way round;")
+print("          attention pieces: S^T | band | mask, max, exp, sum | P V + store")
+for w in (0, 1, 4, 5):
     s = a[w]
     used = [i for i in range(32) if s[i, 0]]
-    print(f"wave {w}: {len(used)} head iterations; ticks per piece: " + " ".join(f"{v:>5s}" for v in names) + " |   head")
-    for i in used[:14]:
+    print(f"wave {w}: {len(used)} items; ticks:  late   epi  KVbar  reg-1  reg-2 close |   item     attention: S^T  band  smax  PV+st")
+    rows = []
+    for i in used[:30]:
         r = s[i]
-        d = [int(r[k + 1] - r[k]) if r[k + 1] and r[k] else 0 for k in range(13)]
-        print(f"  it {i:2d}: " + " " * 22 + " ".join(f"{v:5d}" for v in d) + f" | {int(r[13] - r[0]):6d}")
-    m = np.array([[int(s[i][k + 1] - s[i][k]) for k in range(13)] for i in used[1:11]])
-    print("  mean:  " + " " * 22 + " ".join(f"{v:5.0f}" for v in m.mean(axis=0)) + f" | {m.sum(axis=1).mean():6.0f}")
+        d = [int(r[k + 1] - r[k]) if r[k + 1] and r[k] else 0 for k in range(6)]
+        nxt = int(s[i + 1][0] - r[0]) if i + 1 < 32 and s[i + 1][0] else 0
+        t0 = r[3] if w < 4 else r[4]   # start of this wave's attention
+        t1 = r[4] if w < 4 else r[5]
+        at = [int(r[9] - t0), int(r[10] - r[9]), int(r[11] - r[10]), int(t1 - r[11])] if r[9] and r[10] and r[11] else [0, 0, 0, 0]
+        rows.append(d + [nxt] + at)
+        if i < 6 or i in (11, 12):
+            print(f"  item {i:2d}:       " + " ".join(f"{v:5d}" for v in d) + f" | {nxt:6d}                 " + " ".join(f"{v:5d}" for v in at))
+    m = np.array(rows[1:11])
+    print("  mean 1-10:     " + " ".join(f"{v:5.0f}" for v in m[:, :6].mean(axis=0)) + f" | {m[:, 6].mean():6.0f}                 " + " ".join(f"{v:5.0f}" for v in m[:, 7:].mean(axis=0)))

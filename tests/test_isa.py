@@ -256,3 +256,45 @@ def test_fused_attention_kernel_has_no_scratch_and_never_drains_the_weight_strea
     for m in re.finditer(r"\.name:\s+_ZN4fdmi2sa15seq_attn_kernelILi(\d+)ELb0EEEvNS_11SeqAttnArgsE\n(.*?)\.wavefront_size", asm, re.S):
         fields = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(2))}
         assert fields["private_segment_fixed_size"] <= 64 and fields["vgpr_spill_count"] <= 12, fields
+
+
+# ------------------------------------------------------------ seq_attn16.hip (round 6)
+def test_sixteen_row_fused_attention_kernel_is_spill_free_and_keeps_its_weight_stream_counted(tmp_path):
+    """s16::seq_attn16_kernel (d_model 384 and 192), the default fused projection + attention kernel since round 6: two waves per SIMD,
+    256 registers each, 96 of them the hidden state.  A spill is a vector-memory load behind s_waitcnt vmcnt(0) in the middle of the
+    counted LDS-DMA weight stream (every structure tried on the way that spilled lost the stream: profiles/r06_seq_attn16_notes.log).
+    Pinned for the production instantiations: no scratch at all, <= 256 VGPRs, exactly the hand-written vector-memory waits inside
+    the item loop (one vmcnt(0) per item in front of the K / V barrier, counted waits everywhere else), no packed fp32 arithmetic
+    (it serializes with the partner wave's MFMAs), every contraction on v_mfma_f32_16x16x32_f16, the wide-store hazard scan clean."""
+    try:
+        hipcc = fbuild.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    out = tmp_path / "seq_attn16.s"
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include")] \
+        + fbuild.PER_SOURCE_FLAGS.get("seq_attn16", []) \
+        + ["-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, "seq_attn16.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert wide_store_hazards(asm) == []
+    found = 0
+    for m in re.finditer(r"^(_ZN4fdmi3s1617seq_attn16_kernelILi(\d+)ELb0EEEvNS_11SeqAttnArgsE):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
+        nkt, body = int(m.group(2)), m.group(3)
+        found += 1
+        assert "scratch_" not in body, nkt
+        assert "v_accvgpr" not in body, nkt   # accumulators live in VGPRs: no copies out of the accumulator file
+        assert not re.search(r"v_pk_(fma|mul|add)_f32", body), nkt
+        assert "v_mfma_f32_32x32" not in body and body.count("v_mfma_f32_16x16x32_f16") >= 18 * nkt + 75, nkt
+        # every vector-memory wait of the kernel is hand written: counted waits (2: the ctx stores, 3: the pieces of the next stage) and
+        # vmcnt(0) only where nothing may be in flight -- the two table-fill loops, the prologue, the K / V barrier, the kernel's end
+        # (d_model 192: three stages per head, the newest request IS the stage a top waits for: its tops are vmcnt(0) by design)
+        waits = [int(x) for x in re.findall(r"s_waitcnt\s+vmcnt\((\d+)\)", body)]
+        assert set(waits) <= {0, 2, 3}, (nkt, sorted(set(waits)))
+        if nkt == 12:
+            assert waits.count(0) <= 6, (nkt, waits)
+        assert body.count("s_barrier") >= (nkt // 2 - 2) + 2, nkt
+    assert found == 2
+    for m in re.finditer(r"\.name:\s+_ZN4fdmi3s1617seq_attn16_kernelILi(\d+)ELb0EEEvNS_11SeqAttnArgsE\n(.*?)\.wavefront_size", asm, re.S):
+        fields = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(2))}
+        assert fields["private_segment_fixed_size"] == 0 and fields["vgpr_spill_count"] == 0 and fields["vgpr_count"] <= 256, fields
