@@ -54,7 +54,7 @@ HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: measured float4 copy
 PRECISION_INFO = {
     "f32": dict(peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
                 kernel="gemm_f32_kernel<2,2,2,2,32,EPI_BIAS> (QKV projection, M=B*L, N=1152, K=384; v_mfma_f32_32x32x2_f32)"),
-    "f16x3": dict(peak=PEAK_F16_MFMA_TFLOPS, dtype="f32 (fp16 hi/lo split operands, 3x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
+    "f16x3": dict(peak=PEAK_F16_MFMA_TFLOPS, dtype="f32 (fp16 hi/lo split operands, 3x v_mfma_f32_{32x32x16,16x16x32}_f16 per product, fp32 accumulate)",
                   kernel="gi::gemm_img_kernel<EPI_IMG_QKV> = 128x384-tile LDS-DMA-staged split GEMM on fp16 hi|lo grouped row images (q|k|v "
                          "projection in one launch, M=B*L, N=1152, K=384; algorithmic FLOPs counted once, the 3 MFMAs per product are overhead "
                          "against the dense fp16 peak)"),
@@ -316,7 +316,7 @@ def main():
     legacy_fused = os.environ.get("FDMI_FUSE_ATTN") == "2"
     dom_kernel = pinfo["kernel"]
     if dom_name == "qkv_attention_fused":
-        dom_kernel = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_32x32x16_f16 per product)" if legacy_fused else
+        dom_kernel = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_{32x32x16,16x16x32}_f16 per product)" if legacy_fused else
                       "s16::seq_attn16_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, 16-row waves, "
                       "two per SIMD, fp16 hi/lo split, 3x v_mfma_f32_16x16x32_f16 per product)")
     traffic, traffic_note = None, "not measured (--no-traffic, N > 1 or another shape)"

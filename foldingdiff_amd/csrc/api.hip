@@ -760,7 +760,9 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
         PROF(KC_SEQ_ATTN, launched = launch_seq_attn16(a, s));
         if (!launched) return fail(FD_E_HIP, "the fused projection + attention kernel could not be launched (%d bytes of LDS per workgroup)", 160256);
       } else {
-        PROF(KC_SEQ_ATTN, launch_seq_attn(a, s));
+        bool launched = false;
+        PROF(KC_SEQ_ATTN, launched = launch_seq_attn(a, s));
+        if (!launched) return fail(FD_E_HIP, "the 32-row fused projection + attention kernel could not be launched (%d bytes of LDS per workgroup)", 160 * 1024);
       }
       DBG_STOP();
       DBG_STOP();  // (two launches of the other path: debug_stop counts stay comparable)
@@ -1464,10 +1466,12 @@ int fd_forward_ex(fd_model* m, const float* x, int t, const uint8_t* key_mask, c
   if (key_mask && !w.kmask) HIP_TRY(hipMalloc((void**)&w.kmask, (size_t)B * L));
   if (position_ids && c.pos_type == FD_POS_ABSOLUTE && !w.pos_ids) HIP_TRY(hipMalloc((void**)&w.pos_ids, (size_t)B * L * 4));
   std::vector<int32_t> lens(B, L);  // every position is a row and a key; what is attended to is the mask's business
-  HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
-  // (a blocking copy: `lens` is a pageable vector of this frame, and the early returns below would destroy it under an
-  // asynchronous one)
+  // `lens` is a pageable vector of this frame, and the early returns below would destroy it under an asynchronous copy: a blocking
+  // one -- which goes through the NULL stream and is not ordered against work still queued on the model's non-blocking stream (an
+  // earlier asynchronous entry point reading w.lens), so that stream is drained first
+  HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(w.lens, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(w.x, x, n * 4, hipMemcpyHostToDevice, s));
   StepMode mode{};
   mode.forward_only = true;
   if (key_mask) {

@@ -190,7 +190,7 @@ struct SeqAttnArgs {
   unsigned long long* stamps;  // null, or [4 waves][64 slots][16] cycle stamps of workgroup 0 (debug)
 };
 bool seq_attn_supported(int d_model, int n_heads, int L, int maxpos);
-void launch_seq_attn(const SeqAttnArgs& p, hipStream_t s);
+bool launch_seq_attn(const SeqAttnArgs& p, hipStream_t s);   // false: the LDS opt-in or the launch was refused
 // seq_attn16.hip (round 6): the same operation with 16-row waves, two per SIMD (v_mfma_f32_16x16x32_f16); wimg = [head][k32 step][tile]
 // [unit][row][16 B] (api.hip: upload_seq_attn16_weights); any L <= 128, padded or packed rows.  false: the launch failed.
 bool seq_attn16_supported(int d_model, int n_heads, int L, int maxpos);

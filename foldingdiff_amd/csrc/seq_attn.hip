@@ -922,20 +922,24 @@ static int n_cu_of(int dev) {
 }
 
 template <int NKT>
-static void launch(const SeqAttnArgs& p, hipStream_t s) {
+static bool launch(const SeqAttnArgs& p, hipStream_t s) {
   static bool attr_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attn_kernel<NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attn_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  if (!attr_set[dev]) {   // the whole LDS of a CU: a runtime that refuses the opt-in must surface here, not as a silent no-op launch
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attn_kernel<NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attn_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
     attr_set[dev] = true;
   }
   int grid = n_cu_of(dev);
   if (grid > p.B) grid = p.B;
   if (p.stamps) hipLaunchKernelGGL((seq_attn_kernel<NKT, true>), dim3(grid), dim3(256), SMEM, s, p);
   else hipLaunchKernelGGL((seq_attn_kernel<NKT, false>), dim3(grid), dim3(256), SMEM, s, p);
+  return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace sa
@@ -946,9 +950,8 @@ bool seq_attn_supported(int d_model, int n_heads, int L, int maxpos) {
   return (d_model == 384 || d_model == 192) && n_heads * 32 == d_model && L > 96 && L <= 128 && maxpos <= 128 && maxpos >= L;
 }
 
-void launch_seq_attn(const SeqAttnArgs& p, hipStream_t s) {
-  if (p.H == 12) sa::launch<12>(p, s);
-  else sa::launch<6>(p, s);
+bool launch_seq_attn(const SeqAttnArgs& p, hipStream_t s) {
+  return p.H == 12 ? sa::launch<12>(p, s) : sa::launch<6>(p, s);
 }
 
 }  // namespace fdmi

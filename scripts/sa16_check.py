@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from foldingdiff_amd import _binding, beta_schedules, modelling  # noqa: E402
 from oracle import ref_model, ref_sampling  # noqa: E402

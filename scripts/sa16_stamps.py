@@ -7,7 +7,7 @@ import sys
 
 os.environ["FDMI_STAMPS"] = "1"
 os.environ.setdefault("FDMI_FUSE_ATTN", "1")
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

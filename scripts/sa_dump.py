@@ -10,7 +10,7 @@ os.environ["FDMI_STAMPS"] = "1"
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from foldingdiff_amd import _binding, beta_schedules, modelling  # noqa: E402
 from oracle import ref_model, ref_sampling  # noqa: E402
@@ -38,7 +38,7 @@ sa.key.register_forward_hook(lambda m, a, o: cap.__setitem__("k", o.detach().dou
 sa.value.register_forward_hook(lambda m, a, o: cap.__setitem__("v", o.detach().double()))
 oracle(x, t, attention_mask=mask)
 E = sa.distance_embedding.weight.detach().double()
-pm.set_option("fuse_attn", 1)
+pm.set_option("fuse_attn", 2)   # the 32-row kernel (seq_attn.hip)
 pm.set_option("use_graph", 0)
 pm(x, t, attention_mask=mask)
 n0 = 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16

@@ -7,8 +7,8 @@ import os
 import sys
 
 os.environ["FDMI_STAMPS"] = "1"
-os.environ.setdefault("FDMI_FUSE_ATTN", "1")
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FDMI_FUSE_ATTN", "2")   # the 32-row kernel (seq_attn.hip); sa16_stamps.py is the 16-row one
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
