@@ -316,7 +316,7 @@ def main():
     legacy_fused = os.environ.get("FDMI_FUSE_ATTN") == "2"
     dom_kernel = pinfo["kernel"]
     if dom_name == "qkv_attention_fused":
-        dom_kernel = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_{32x32x16,16x16x32}_f16 per product)" if legacy_fused else
+        dom_kernel = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_32x32x16_f16 per product)" if legacy_fused else
                       "s16::seq_attn16_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, 16-row waves, "
                       "two per SIMD, fp16 hi/lo split, 3x v_mfma_f32_16x16x32_f16 per product)")
     traffic, traffic_note = None, "not measured (--no-traffic, N > 1 or another shape)"

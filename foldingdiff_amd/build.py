@@ -20,7 +20,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfdmi.so")
-SOURCES = ["api.hip", "gemm_f32.hip", "gemm_img.hip", "gemm_ws.hip", "gemm_ln_rows.hip", "attention_f32.hip", "attention_img.hip", "attention_gen.hip", "seq_attn.hip", "seq_attn16.hip", "rowwise.hip",
+SOURCES = ["api.hip", "gemm_f32.hip", "gemm_img.hip", "gemm_ws.hip", "gemm_ln_rows.hip", "attention_f32.hip", "attention_img.hip", "attention_gen.hip", "seq_attn.hip", "seq_attn16.hip", "ffn16.hip", "rowwise.hip",
            "rowwise_img.hip", "nerf.hip"]
 HEADERS = [os.path.join(CSRC, "fdmi_kernels.h"), os.path.join(CSRC, "img_common.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "fdmi.h")]
@@ -33,6 +33,7 @@ PER_SOURCE_FLAGS = {
     "attention_gen": ["-fno-slp-vectorize"],
     "seq_attn": ["-fno-slp-vectorize"],
     "seq_attn16": ["-fno-slp-vectorize"],
+    "ffn16": ["-fno-slp-vectorize"],
 }
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -111,7 +112,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     return lib_path
 
 
-MFMA_SOURCES = ["seq_attn16.hip", "seq_attn.hip", "gemm_img.hip", "attention_img.hip"]
+MFMA_SOURCES = ["seq_attn16.hip", "ffn16.hip", "seq_attn.hip", "gemm_img.hip", "attention_img.hip"]
 
 
 def mfma_counts(defines=(), paths=None) -> dict:

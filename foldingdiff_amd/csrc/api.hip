@@ -55,6 +55,8 @@ struct LayerDev {
   // activation images -- derived from norm bounds of the weights at fd_finalize, so nothing can overflow fp16
   SplitW wqk_i, wv_i, wqkv_i, wo_i, wi_i, wd_i;  // wqkv_i: q | k | v rows in one image (n_heads % 6 == 0: one launch)
   SplitW wsa_i;  // the same q | k | v weights ordered per head for the 32-row fused projection + attention kernel (seq_attn.hip), or null
+  SplitW wff_i;    // intermediate.dense + output.dense as ONE stream of ring stages (ffn16.hip), or null; scale = the first dense's
+  float wff_scale_dn = 1.f;  // ... the second dense's
   SplitW wsa16_i;  // ... for the 16-row kernel (seq_attn16.hip: rows of a head permuted into its operand tiles), or null
   float *bqk = nullptr, *bv = nullptr;  // bias slices of bqkv
   float s_h = 1.f, s_q = 1.f, s_k = 1.f, s_v = 1.f, s_a = 1.f, s_g = 1.f;
@@ -65,11 +67,11 @@ struct LayerDev {
 
 enum KClass {
   KC_EMBED = 0, KC_GEMM_QKV, KC_GEMM_V, KC_ATTN, KC_GEMM_OUT, KC_LN1, KC_GEMM_UP, KC_GEMM_DOWN, KC_LN2, KC_GEMM_HEAD,
-  KC_HEAD_UPDATE, KC_ADVANCE, KC_SEQ_ATTN, KC_COUNT
+  KC_HEAD_UPDATE, KC_ADVANCE, KC_SEQ_ATTN, KC_FFN, KC_COUNT
 };
 const char* const kClassName[KC_COUNT] = {
     "embed_ln_time", "gemm_qkv", "gemm_v", "attention", "gemm_attn_out", "layernorm_attn", "gemm_ffn_up",
-    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance", "qkv_attention_fused"};
+    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance", "qkv_attention_fused", "ffn_fused"};
 
 struct Workspace {
   int B = 0, L = 0;
@@ -91,6 +93,7 @@ struct Workspace {
   int graph_fuse_ln = -2;  // option value the graph was captured with (-2: none)
   int graph_varlen = -1;   // ... and the row mode (packed rows launch the slice-capable GEMM instantiation)
   int graph_fuse_attn = -2;  // ... and the fused projection + attention choice
+  int graph_fuse_ffn = -2;   // ... and the fused feed-forward choice
   uint64_t last_use = 0;
   void release() {
     if (graph) (void)hipGraphExecDestroy(graph);
@@ -104,7 +107,7 @@ struct Workspace {
   }
 };
 
-constexpr long long kStampWords = 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16 + 16384;  // (+ 32 K floats of register dumps, seq_attn.hip FDMI_SA_DUMP)
+constexpr long long kStampWords = 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16 + 16384 + 8 * 16 * 16;  // (... + ffn16.hip's [8][16][16])  // (+ 32 K floats of register dumps, seq_attn.hip FDMI_SA_DUMP)
 
 struct PendingEvent {
   int cls;
@@ -141,6 +144,8 @@ struct fd_model {
   int varlen = 0;    // row-image path: only the first lens[b] positions of a sequence are token rows
   int fuse_attn = -1;  // row-image path: q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): -1 auto (padded rows of
                      // 97 .. 128 positions), 0 never, 1 wherever the kernel applies (packed rows too)
+  int fuse_ffn = -1;   // row-image path: BertIntermediate + BertOutput as ONE kernel (ffn16.hip): -1 auto (whole rounds of 128-row passes), 0 never,
+                     // 1 wherever the kernel applies
   // workspaces (buffers + captured graph) are kept per (B, L): sample_length()-driven sampling and ragged chunks
   // alternate between a few shapes
   std::vector<Workspace> cache;
@@ -286,6 +291,44 @@ int upload_seq_attn16_weights(fd_model* m, SplitW* dst, const float* W, int d) {
   return FD_OK;
 }
 
+// ffn16.hip's weights: intermediate.dense [ff][d] and output.dense [d][ff] as ONE stream in consumption order.  Per group G of 64
+// intermediate features: d / 32 steps of the first dense (k32 step ks: four tiles, tile t = 2 pair + j, row i = feature
+// 64 G + 32 pair + 8 (i / 4) + 4 j + (i % 4)), then d / 32 steps of the second (pair 0, 1: its 32 features are one k32 step; output
+// tiles T = 0 .. d / 16 - 1 four to a step, tile T = 2 kt + j, row i = output feature 32 kt + 8 (i / 4) + 4 j + (i % 4)).  A tile =
+// [unit 0-7][row 0-15][16 B] (units 0-3: hi of k 8 u .. 8 u + 7, 4-7: lo), a step = 8 KiB, two steps = one LDS ring stage byte for
+// byte.  Each matrix is split at its own power-of-two scale.
+int upload_ffn16_weights(fd_model* m, LayerDev* lw, const float* Wi, const float* Wd, int d, int ff) {
+  std::vector<uint16_t> ri, rd, img;
+  pack_split_weight(Wi, ff, d, &ri, &lw->wff_i.scale, 128);
+  pack_split_weight(Wd, d, ff, &rd, &lw->wff_scale_dn, 128);
+  const int nkt = d / 32, ng = ff / 64, spg = 2 * nkt, nkd = ff / 32;
+  img.assign((size_t)ng * spg * 4 * 1024, 0);
+  auto put = [&](int G, int step, int t, int i, const uint16_t* blk) {
+    uint16_t* tile = img.data() + (((size_t)G * spg + step) * 4 + t) * 1024;
+    for (int u = 0; u < 8; ++u) memcpy(tile + ((size_t)u * 16 + i) * 8, blk + u * 8, 16);
+  };
+  for (int G = 0; G < ng; ++G) {
+    for (int ks = 0; ks < nkt; ++ks)
+      for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 16; ++i) {
+          const int f = 64 * G + 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
+          put(G, ks, t, i, ri.data() + ((size_t)f * nkt + ks) * 64);
+        }
+    for (int pr = 0; pr < 2; ++pr)
+      for (int T = 0; T < 2 * nkt; ++T)
+        for (int i = 0; i < 16; ++i) {
+          const int o = 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3);
+          put(G, nkt + pr * (nkt / 2) + T / 4, T % 4, i, rd.data() + ((size_t)o * nkd + 2 * G + pr) * 64);
+        }
+  }
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, img.size() * 2));
+  m->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  lw->wff_i.p = p;
+  return FD_OK;
+}
+
 void free_weights(fd_model* m) {
   for (void* p : m->allocs) (void)hipFree(p);
   m->allocs.clear();
@@ -426,6 +469,8 @@ int ensure_ws(fd_model* m, int B, int L) {
     fl[KC_ADVANCE] = 0;                        by[KC_ADVANCE] = 4;
     // fused q | k | v projection + attention: h in, ctx out, the weights once (q, k, v stay on chip)
     fl[KC_SEQ_ATTN] = 2 * Md * 3 * dd * dd + 6 * Ld * dd * Md;  by[KC_SEQ_ATTN] = 4 * (2 * Md * dd + 3 * dd * dd);
+    // fused BertIntermediate + BertOutput: a in, h out, both weight matrices once (the intermediate stays on chip)
+    fl[KC_FFN] = 4 * Md * ff * dd;             by[KC_FFN] = 4 * (2 * Md * dd + 2 * ff * dd);
   }
   w.last_use = ++m->use_clock;
   if (w.B == B && w.L == L) return FD_OK;
@@ -838,6 +883,37 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       }
       DBG_STOP();
     }
+    // BertIntermediate + BertOutput as ONE kernel (ffn16.hip): the 2 d wide intermediate never reaches HBM.  Passes of 128 rows, one
+    // workgroup per CU: auto = the passes fill whole rounds of the CUs (512 passes on 256 CUs: two; 315 would leave the second round
+    // a quarter full where the tile GEMMs deal 6 + 1 column tiles per pass)
+    static const int fuse_ffn_env = [] { const char* e = getenv("FDMI_FUSE_FFN"); return e ? atoi(e) : -1; }();
+    const int fuse_ffn = m->fuse_ffn >= 0 ? m->fuse_ffn : fuse_ffn_env;
+    bool ffn_auto = false;
+    {
+      const int ncu = gemm_img_grid(1 << 30, 384), passes = max_rows / 128;
+      const int rounds = (passes + ncu - 1) / ncu;
+      ffn_auto = (double)passes >= 0.94 * (double)rounds * ncu;
+    }
+    const bool fused_ffn = fuse_ffn != 0 && (fuse_ffn > 0 || ffn_auto) && lw.wff_i.p && ffn16_supported(d, ff) &&
+                           (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
+    if (fused_ffn) {
+      FfnArgs a;
+      memset(&a, 0, sizeof a);
+      a.aimg = w.aimg; a.a_bytes = (unsigned)((size_t)w.cap * d * 4);
+      a.wimg = static_cast<const unsigned char*>(lw.wff_i.p);
+      a.bi = lw.bi; a.bd = lw.bd; a.gamma = lw.ln2g; a.beta = lw.ln2b;
+      a.out = w.himg; a.out_bytes = a.a_bytes;
+      a.panels = max_rows / 128;
+      a.up_scale = 1.0f / (lw.s_a * lw.wff_i.scale); a.g_scale = lw.s_g; a.down_scale = 1.0f / (lw.s_g * lw.wff_scale_dn);
+      a.resid_inv = 1.0f / lw.s_a; a.out_scale = s_next; a.eps = c.ln_eps;
+      a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16 + 16384 : nullptr;
+      bool launched = false;
+      PROF(KC_FFN, launched = launch_ffn16(a, d, s));
+      if (!launched) return fail(FD_E_HIP, "the fused feed-forward kernel could not be launched");
+      DBG_STOP();
+      DBG_STOP();  // (two launches of the other path: debug_stop counts stay comparable)
+      continue;
+    }
     {
       GemmImgArgs g = base();
       g.A = w.aimg; g.W = static_cast<const unsigned char*>(lw.wi_i.p); g.bias = lw.bi; g.out = w.gimg; g.N = ff; g.K = d;
@@ -944,7 +1020,7 @@ int check_lens(const int32_t* lens, int B, int L) {
 
 // the workspace's captured graph still holds the launch sequence the model's options ask for
 static bool graph_current(const fd_model* m, const Workspace& w) {
-  return w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn;
+  return w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn && w.graph_fuse_ffn == m->fuse_ffn;
 }
 
 int ensure_graph(fd_model* m) {
@@ -980,6 +1056,7 @@ int ensure_graph(fd_model* m) {
   w.graph_fuse_ln = m->fuse_ln;
   w.graph_varlen = m->varlen;
   w.graph_fuse_attn = m->fuse_attn;
+  w.graph_fuse_ffn = m->fuse_ffn;
   return FD_OK;
 }
 
@@ -1342,6 +1419,9 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
       if (int rc = upload_split(m, &lw.wo_i, wo->data.data(), (int)d, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wi_i, wi->data.data(), (int)ff, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wd_i, wd->data.data(), (int)d, (int)ff, 384)) return rc;
+      lw.wff_i = SplitW();
+      if (ffn16_supported((int)d, (int)ff))
+        if (int rc = upload_ffn16_weights(m, &lw, wi->data.data(), wd->data.data(), (int)d, (int)ff)) return rc;
       const Bound ab = ln_bound(g1, b1);
       lw.s_a = scale_for(ab.linf);
       lw.s_g = scale_for(dense_bound(wi->data.data(), bi->data.data(), 0, (int)ff, (int)d, ab.l2));  // |gelu(u)| <= |u|
@@ -1402,6 +1482,7 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
   else if (n == "varlen") m->varlen = value ? 1 : 0;
   else if (n == "fuse_attn") m->fuse_attn = value < 0 ? -1 : (value > 2 ? 1 : value);
+  else if (n == "fuse_ffn") m->fuse_ffn = value < 0 ? -1 : (value ? 1 : 0);
   else if (n == "split_qkv") {
     m->split_qkv = value ? 1 : 0;
     drop_workspaces(m);  // captured graphs hold the other launch sequence

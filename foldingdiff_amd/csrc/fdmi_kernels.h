@@ -196,6 +196,30 @@ bool launch_seq_attn(const SeqAttnArgs& p, hipStream_t s);   // false: the LDS o
 bool seq_attn16_supported(int d_model, int n_heads, int L, int maxpos);
 bool launch_seq_attn16(const SeqAttnArgs& p, hipStream_t s);
 
+// ffn16.hip (round 6): BertIntermediate + GELU + BertOutput (dense + residual + LayerNorm) of 128 token rows per pass in ONE kernel;
+// the intermediate never reaches HBM.  wimg = ONE stream of 24 KiB stages in consumption order (api.hip: upload_ffn16_weights).
+struct FfnArgs {
+  const unsigned char* aimg;   // input image [rows128][d/32] (BertSelfOutput's LayerNorm output): operand AND residual
+  unsigned a_bytes;            // its size (rows beyond it read as zeros)
+  const unsigned char* wimg;   // weight stream
+  const float* bi;             // [2 d]  intermediate.dense.bias
+  const float* bd;             // [d]    output.dense.bias
+  const float* gamma;          // [d]    output.LayerNorm
+  const float* beta;
+  unsigned char* out;          // output image [rows128][d/32] (must not alias aimg)
+  unsigned out_bytes;          // its size (stores beyond it are dropped)
+  int panels;                  // passes of 128 rows
+  float up_scale;              // 1 / (scale of aimg * scale of the first dense's weights)
+  float g_scale;               // scale of the intermediate's hi / lo images (a power of two)
+  float down_scale;            // 1 / (g_scale * scale of the second dense's weights)
+  float resid_inv;             // 1 / scale of aimg
+  float out_scale;             // scale of the output image
+  float eps;
+  unsigned long long* stamps;  // null, or [8 waves][16 passes][16] cycle stamps of workgroup 0 (debug)
+};
+bool ffn16_supported(int d_model, int d_ff);
+bool launch_ffn16(const FfnArgs& p, int d_model, hipStream_t s);   // false: the launch failed
+
 struct EmbedImgArgs {
   const float* x;              // [B][L][F]
   const float* w_in; const float* b_in; const float* pos_emb; const float* gamma; const float* beta;
