@@ -292,7 +292,8 @@ int upload_seq_attn16_weights(fd_model* m, SplitW* dst, const float* W, int d) {
 }
 
 // ffn16.hip's weights: intermediate.dense [ff][d] and output.dense [d][ff] as ONE stream in consumption order.  Per group G of 64
-// intermediate features: d / 32 steps of the first dense (k32 step ks: four tiles, tile t = 2 pair + j, row i = feature
+// intermediate features (the first dense runs one group ahead of the second: up(0) | up(1) down(0) | ... | up(ng - 1) down(ng - 2) |
+// down(ng - 1)): d / 32 steps of the first dense (k32 step ks: four tiles, tile t = 2 pair + j, row i = feature
 // 64 G + 32 pair + 8 (i / 4) + 4 j + (i % 4)), then d / 32 steps of the second (pair 0, 1: its 32 features are one k32 step; output
 // tiles T = 0 .. d / 16 - 1 four to a step, tile T = 2 kt + j, row i = output feature 32 kt + 8 (i / 4) + 4 j + (i % 4)).  A tile =
 // [unit 0-7][row 0-15][16 B] (units 0-3: hi of k 8 u .. 8 u + 7, 4-7: lo), a step = 8 KiB, two steps = one LDS ring stage byte for
@@ -303,8 +304,11 @@ int upload_ffn16_weights(fd_model* m, LayerDev* lw, const float* Wi, const float
   pack_split_weight(Wd, d, ff, &rd, &lw->wff_scale_dn, 128);
   const int nkt = d / 32, ng = ff / 64, spg = 2 * nkt, nkd = ff / 32;
   img.assign((size_t)ng * spg * 4 * 1024, 0);
-  auto put = [&](int G, int step, int t, int i, const uint16_t* blk) {
-    uint16_t* tile = img.data() + (((size_t)G * spg + step) * 4 + t) * 1024;
+  // stream position (in steps) of a group's blocks: up(0) | up(1) down(0) | up(2) down(1) | ... | up(ng - 1) down(ng - 2) | down(ng - 1)
+  auto up_at = [&](int G) { return G == 0 ? 0 : nkt + (G - 1) * spg; };
+  auto down_at = [&](int G) { return G == ng - 1 ? nkt + (ng - 1) * spg : nkt + G * spg + nkt; };
+  auto put = [&](int step, int t, int i, const uint16_t* blk) {
+    uint16_t* tile = img.data() + ((size_t)step * 4 + t) * 1024;
     for (int u = 0; u < 8; ++u) memcpy(tile + ((size_t)u * 16 + i) * 8, blk + u * 8, 16);
   };
   for (int G = 0; G < ng; ++G) {
@@ -312,13 +316,13 @@ int upload_ffn16_weights(fd_model* m, LayerDev* lw, const float* Wi, const float
       for (int t = 0; t < 4; ++t)
         for (int i = 0; i < 16; ++i) {
           const int f = 64 * G + 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
-          put(G, ks, t, i, ri.data() + ((size_t)f * nkt + ks) * 64);
+          put(up_at(G) + ks, t, i, ri.data() + ((size_t)f * nkt + ks) * 64);
         }
     for (int pr = 0; pr < 2; ++pr)
       for (int T = 0; T < 2 * nkt; ++T)
         for (int i = 0; i < 16; ++i) {
           const int o = 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3);
-          put(G, nkt + pr * (nkt / 2) + T / 4, T % 4, i, rd.data() + ((size_t)o * nkd + 2 * G + pr) * 64);
+          put(down_at(G) + pr * (nkt / 2) + T / 4, T % 4, i, rd.data() + ((size_t)o * nkd + 2 * G + pr) * 64);
         }
   }
   void* p = nullptr;

@@ -7,8 +7,8 @@
 // The structure is seq_attn16.hip's projection, twice over: a wave owns SIXTEEN token rows, two waves per SIMD, 256 registers each,
 // every contraction on v_mfma_f32_16x16x32_f16 in the swapped form D^T = W x^T (a lane owns a token):
 //   * the rows' input image (BertSelfOutput's LayerNorm output, hi / lo fp16) is stationary: the hi plane in 48 registers, the lo plane
-//     in LDS (96 KiB per 128 rows, lane-linear per wave: it arrives by LDS-DMA and is read back as the B operand w_hi x_lo needs, one
-//     16-byte read per step -- with both planes in registers hipcc spills the image and reloads it behind vmcnt(0) in every
+//     in LDS (96 KiB per 128 rows, lane-linear per wave: read back as the B operand w_hi x_lo needs, one 16-byte read per
+//     step -- with both planes in registers hipcc spills the image and reloads it behind vmcnt(0) in every
 //     group); B operand of the first dense AND the residual of the second, whose 16 x d output accumulates in 96 registers over
 //     the whole pass;
 //   * the intermediate is produced 64 features (four 16 x 16 tiles) at a time: bias, GELU and the hi / lo split in registers; the weight
@@ -16,7 +16,7 @@
 //     eight consecutive features of its token = one 16-byte B-operand unit of the second dense, whose own output rows are permuted
 //     the same way (= the units of the output image, and of the stationary input image for the residual): no cross-lane traffic;
 //   * both weight matrices arrive as ONE linear stream of 16 KiB stages in consumption order (per 64-feature group: 6 stages of the
-//     first dense, 6 of the second; 144 stages = 2.25 MiB per pass at d_model 384) through a 3-slot LDS ring: LDS-DMA, two 1 KiB
+//     first dense, 6 of the second, the first dense one group ahead: its neighbour's GELU runs inside it; 144 stages = 2.25 MiB per pass at d_model 384) through a 3-slot LDS ring: LDS-DMA, two 1 KiB
 //     pieces per wave and stage, one workgroup barrier per stage, counted s_waitcnt vmcnt (the stream never drains inside a pass
 //     and does not stop at a pass's end); a group is a whole number of ring turns, so every fragment address is an immediate;
 //   * a step = four weight tiles against one B operand pair: 8 fragment reads and 12 MFMAs (w_hi x_hi | w_hi x_lo | w_lo x_hi), the
@@ -146,14 +146,25 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     const int row = r0 + 16 * wq + (ln & 15);
     return (unsigned)(((row >> 5) * (NKT * 256) + (row & 31)) * 16 + (ln >> 4) * 512);
   };
-  auto load_a = [&](int r0) __attribute__((always_inline)) {  // rows beyond the image read as zeros
+  // (The lo plane goes through registers.  Fetched by LDS-DMA with these per-lane offsets it arrived wrong now and then -- behind
+  // vmcnt(0), a barrier and a long sleep: stale LDS contents in ~40 % of the runs of a 6-layer d_model-192 model, never with the
+  // two wave groups' stage tops at the same place; scripts/ffn16_stress.py, profiles/r06_ffn16_notes.log.  Twelve loads and twelve
+  // LDS writes per wave and pass cost nothing.)
+  u32x4 tl[NKT];
+  auto load_hi = [&](int r0) __attribute__((always_inline)) {  // rows beyond the image read as zeros
     const unsigned hoff = row_off(r0);
-    const lds_ptr_t dst = (lds_ptr_t)(unsigned long long)(smem0 + OFF_X + (unsigned)(wq * NKT * 1024));
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt)
       ah[kt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)hoff, kt * 8 * 512, 0));
-      dma16(rs_a, dst + kt * 1024, (int)hoff, (kt * 8 + 4) * 512);
-    }
+  };
+  auto load_lo = [&](auto KT, unsigned hoff) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value;
+    tl[kt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)hoff, (kt * 8 + 4) * 512, 0));
+  };
+  auto commit_lo = [&]() __attribute__((always_inline)) {
+    const unsigned ax = smem0 + OFF_X + (unsigned)(wq * NKT * 1024 + lane_id() * 16);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) *(__attribute__((address_space(3))) u32x4*)(unsigned long long)(ax + (unsigned)(kt * 1024)) = tl[kt];
   };
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
@@ -162,19 +173,29 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
   int slot = 0;
 #define FD_STAMP(i) do { if (PROF) { if (rec && slot < 16 && lane == 0) stp[slot * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define FD_SB() __builtin_amdgcn_sched_barrier(0)
+// (inside iteration 1 of the first pass, into slot 15: 0 top | 2 after the next group's first dense with this group's GELU inside | 3 after
+// this group's second dense)
+#define FD_STAMP_G(i) do { if (PROF) { if (rec && slot == 0 && G == 1 && lane == 0) stp[15 * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
   if ((int)blockIdx.x >= p.panels) return;
   const float os_up = p.up_scale, os_dn = p.down_scale, hs = 0.5f * p.g_scale;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 Y[2 * NKT];  // second dense: out tile T = 2 kt + j, row i = output feature 32 kt + 8 (i / 4) + 4 j + (i % 4)
   f32x4 U[4];        // first dense: tile t = 2 pair + j, row i = intermediate feature 64 G + 32 pair + 8 (i / 4) + 4 j + (i % 4)
-  f16x8 uh[2], ul[2];  // GELU output of the group as B operand pairs: this lane's token, features 64 G + 32 pair + 8 g .. + 7
+  f32x4 Up[4];       // ... of the group before (its GELU runs beside this group's matrix instructions)
+  u32x4 uh[2], ul[2];  // GELU output of a group as B operand pairs: this lane's token, features 64 G + 32 pair + 8 g .. + 7
 
-  load_a((int)blockIdx.x * 128);
+  load_hi((int)blockIdx.x * 128);
+  {
+    const unsigned hoff = row_off((int)blockIdx.x * 128);
+    static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) { load_lo(KT, hoff); });
+  }
   issue_w();
   issue_w();
   issue_w();
-  FD_WAIT_VM(2 * PPW);  // the rows and stage 0 landed (requested in this order; stages 1, 2 may still be in flight)
+  FD_WAIT_VM(3 * PPW);  // the rows landed
+  commit_lo();
+  FD_WAIT_VM(2 * PPW);  // ... and stage 0 (requested in this order; stages 1, 2 may still be in flight)
   barrier_keep_vm();
 
   // ---- steps [S0, S1) of a group (its first stage sits in ring slot 0).  Step s < NKT: first dense, k32 step s (B = the input
@@ -185,10 +206,34 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
   // top overwrites) and in front of the reads of hi(s + 1).  The two waves of a SIMD have it at different places: group 0 in front of
   // the step's eight hi-plane MFMAs, group 1 behind them.  vmcnt retires in order: when a stage is published the only younger
   // requests are the two pieces of the stage after it.
-  auto steps = [&](auto S0, auto S1) __attribute__((always_inline)) {
+  // ---- one eighth of a group's GELU: bias, 0.5 s_g x (1 + erf(x / sqrt 2)) at the scale of the intermediate's image (the operations of
+  // gemm_img.hip's gelu_erf4_scaled), hi / lo split of TWO values = word j of pair pr's B operands.  abq: LDS address of this lane's
+  // eight bias values of pair 0.  Plain fp32 VALU: it issues beside the SIMD's other wave's matrix instructions.
+  auto gelu_piece = [&](auto P, unsigned abq) __attribute__((always_inline)) {
+    constexpr int pc = decltype(P)::value, pr = pc >> 2, j = pc & 3;
+    const u32x2 b = *(const __attribute__((address_space(3))) u32x2*)(unsigned long long)(abq + (unsigned)((32 * pr + 2 * j) * 4));
+    float o0 = __builtin_fmaf(Up[2 * pr + (j >> 1)][2 * (j & 1)], os_up, __builtin_bit_cast(float, (unsigned)b[0]));
+    float o1 = __builtin_fmaf(Up[2 * pr + (j >> 1)][2 * (j & 1) + 1], os_up, __builtin_bit_cast(float, (unsigned)b[1]));
+#if !(FDMI_FFN_DBG & 1)
+    const float h0 = o0 * hs, h1 = o1 * hs;
+    o0 = __builtin_fmaf(h0, erf_rational(o0 * 0.70710678118654752440f), h0);
+    o1 = __builtin_fmaf(h1, erf_rational(o1 * 0.70710678118654752440f), h1);
+#endif
+    unsigned a, c;
+    split_pair(o0, o1, a, c);
+    uh[pr][j] = a;
+    ul[pr][j] = c;
+  };
+
+  auto steps = [&](auto S0, auto S1, auto GEL, unsigned abq) __attribute__((always_inline)) {
     constexpr int s0 = decltype(S0)::value, s1 = decltype(S1)::value;
+    constexpr bool gel = decltype(GEL)::value != 0;
     auto stage_top = [&]() __attribute__((always_inline)) {
+#ifdef FDMI_FFN_SAFE  // debug build: no counted wait
+      FD_WAIT_VM(0);
+#else
       FD_WAIT_VM(PPW);
+#endif
       barrier_keep_vm();
       issue_w();
     };
@@ -219,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
 #if !(FDMI_FFN_DBG & 2)
         constexpr int pr = (s - NKT) / (NKT / 2), q = (s - NKT) % (NKT / 2);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) Y[4 * q + t] = mfma16(f[t], which == 1 ? ul[pr] : uh[pr], Y[4 * q + t]);
+        for (int t = 0; t < 4; ++t) Y[4 * q + t] = mfma16(f[t], __builtin_bit_cast(f16x8, which == 1 ? ul[pr] : uh[pr]), Y[4 * q + t]);
 #endif
       }
     };
@@ -231,7 +276,13 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
       plane_reads(S, IC<1>{}, fy);
       FD_SB();
       if constexpr (top) {
+#if defined(FDMI_FFN_SAMETOP)
+        stage_top();
+#elif defined(FDMI_FFN_SWAPTOP)
+        if (grp != 0) stage_top();
+#elif !defined(FDMI_FFN_LATETOP)
         if (grp == 0) stage_top();
+#endif
       }
 #if FDMI_FFN_PRIO
       __builtin_amdgcn_s_setprio(FDMI_FFN_PRIO);
@@ -242,13 +293,44 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
       __builtin_amdgcn_s_setprio(0);
 #endif
       FD_SB();
+#if defined(FDMI_FFN_LATETOP)
+      if constexpr (top) stage_top();
+#elif defined(FDMI_FFN_SWAPTOP)
       if constexpr (top) {
+        if (grp == 0) stage_top();
+      }
+#elif !defined(FDMI_FFN_SAMETOP)
+      if constexpr (top) {
+#ifdef FDMI_FFN_NOPS
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+#endif
         if (grp != 0) stage_top();
       }
+#endif
       if constexpr (s + 1 < s1) plane_reads(IC<s + 1>{}, IC<0>{}, fx);
       FD_SB();
+      if constexpr (gel) {
+        // the previous group's GELU, an eighth at a time in the steps 1 .. NKT - 2 of this group's first dense.  The two waves of a
+        // SIMD run it at DIFFERENT places of the step: in the same place both would leave the matrix pipe at the same time (measured:
+        // the step then costs its matrix time PLUS both waves' vector time, 758 against 567 cycles).  Group 0: here, beside the
+        // lo-plane instructions of group 1
+        if (grp == 0) {
+          static_for<0, 8>([&](auto P) __attribute__((always_inline)) {
+            if constexpr (1 + decltype(P)::value * (NKT - 2) / 8 == s) gelu_piece(P, abq);
+          });
+        }
+        FD_SB();
+      }
       mm(S, IC<2>{}, fy);
       FD_SB();
+      if constexpr (gel) {  // (group 1: at the end of the step, beside the hi-plane instructions of group 0's next step)
+        if (grp != 0) {
+          static_for<0, 8>([&](auto P) __attribute__((always_inline)) {
+            if constexpr (1 + decltype(P)::value * (NKT - 2) / 8 == s) gelu_piece(P, abq);
+          });
+        }
+        FD_SB();
+      }
     });
   };
 
@@ -256,44 +338,36 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     FD_STAMP(0);
 #pragma unroll
     for (int t = 0; t < 2 * NKT; ++t) Y[t] = zero4;
+    // Software pipeline over the groups: the first dense of group G + 1 runs BEFORE the second dense of group G, and the GELU of group G
+    // sits inside it (the weight stream is ordered that way: up(0) | up(1) down(0) | up(2) down(1) | ... | up(NG - 1) down(NG - 2) |
+    // down(NG - 1)).  In sequence (first dense, GELU, second dense) both waves of a SIMD would run their GELU at the same time with
+    // the matrix pipe idle: 3.4 k of a group's 15.9 k cycles (profiles/r06_ffn16_notes.log).
+#pragma unroll
+    for (int t = 0; t < 4; ++t) U[t] = zero4;
+    steps(IC<0>{}, IC<NKT>{}, IC<0>{}, 0u);
     for (int G = 0; G < NG; ++G) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) U[t] = zero4;
-      steps(IC<0>{}, IC<NKT>{});
-      // ---- bias, GELU at the scale of the intermediate's image (0.5 s_g x (1 + erf(x / sqrt 2)): the same operations as
-      // gemm_img.hip's gelu_erf4_scaled), hi / lo split: the B operand pairs of the second dense
-      {
-        const int ln = lane_id();
-        const unsigned bq = smem0 + OFF_P + (unsigned)((64 * G + 8 * (ln >> 4)) * 4);
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const u32x4 b0 = lds_u128(bq + (unsigned)(pr * 128)), b1 = lds_u128(bq + (unsigned)(pr * 128 + 16));
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = __builtin_fmaf(U[2 * pr][e], os_up, __builtin_bit_cast(float, (unsigned)b0[e]));
-            o[4 + e] = __builtin_fmaf(U[2 * pr + 1][e], os_up, __builtin_bit_cast(float, (unsigned)b1[e]));
-          }
-#if !(FDMI_FFN_DBG & 1)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float h = o[e] * hs;
-            o[e] = __builtin_fmaf(h, erf_rational(o[e] * 0.70710678118654752440f), h);
-          }
-#endif
-          u32x4 hv, lv;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            unsigned a, b;
-            split_pair(o[2 * j], o[2 * j + 1], a, b);
-            hv[j] = a;
-            lv[j] = b;
-          }
-          uh[pr] = __builtin_bit_cast(f16x8, hv);
-          ul[pr] = __builtin_bit_cast(f16x8, lv);
-        }
+      for (int t = 0; t < 4; ++t) {
+        Up[t] = U[t];
+        U[t] = zero4;
       }
-      steps(IC<NKT>{}, IC<SPG>{});
+      unsigned abq = smem0 + OFF_P + (unsigned)((64 * G + 8 * (lane_id() >> 4)) * 4);
+      asm volatile("" : "+v"(abq));
+      FD_STAMP_G(0);
+      FD_STAMP_G(1);
+      if (G + 1 < NG) {
+#ifdef FDMI_FFN_NOPIPE  // A/B build: the GELU on its own, in front of the next group's first dense
+        static_for<0, 8>([&](auto P) __attribute__((always_inline)) { gelu_piece(P, abq); });
+        steps(IC<0>{}, IC<NKT>{}, IC<0>{}, abq);
+#else
+        steps(IC<0>{}, IC<NKT>{}, IC<1>{}, abq);
+#endif
+      } else {
+        static_for<0, 8>([&](auto P) __attribute__((always_inline)) { gelu_piece(P, abq); });
+      }
+      FD_STAMP_G(2);
+      steps(IC<NKT>{}, IC<SPG>{}, IC<0>{}, 0u);
+      FD_STAMP_G(3);
       if (slot == 0) FD_STAMP(1 + (G < 12 ? G : 11));
     }
     // ---- dense + bias + residual, LayerNorm, the output image (BertOutput): v = acc / (s_g s_w) + b_d + (hi + lo) / s_a
@@ -328,8 +402,8 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
       }
       // the rows are done with the input image: the next pass's rows replace it under the LayerNorm
       const int next = panel + (int)gridDim.x;
-      FD_WAIT_LGKM0();  // (the lo plane has been read: the requests below overwrite it)
-      if (next < p.panels) load_a(next * 128);
+      load_hi(next * 128);  // (the lo plane: block by block behind the stores below, into the registers they free)
+      const unsigned noff = row_off(next * 128);
       const float inv_n = 1.0f / (float)D;
       float mean = quad_sum(sum) * inv_n;
       asm volatile("" : "+v"(mean));
@@ -344,8 +418,8 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
         }
       const float rstd = (1.0f / sqrtf(__builtin_fmaf(quad_sum(t2), inv_n, p.eps))) * p.out_scale;
       const unsigned ooff = row_off(panel * 128);
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
+      static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) {
+        constexpr int kt = decltype(KT)::value;
         const u32x4 g0 = lds_u128(pb + (unsigned)(D * 4 + kt * 128)), g1 = lds_u128(pb + (unsigned)(D * 4 + kt * 128 + 16));
         const u32x4 e0 = lds_u128(pb + (unsigned)(2 * D * 4 + kt * 128)), e1 = lds_u128(pb + (unsigned)(2 * D * 4 + kt * 128 + 16));
         float o[8];
@@ -364,15 +438,19 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
         }
         __builtin_amdgcn_raw_buffer_store_b128(hv, rs_o, (int)ooff, kt * 8 * 512, 0);
         __builtin_amdgcn_raw_buffer_store_b128(lv, rs_o, (int)ooff, (kt * 8 + 4) * 512, 0);
-      }
+        load_lo(KT, noff);  // (unconditionally: beyond the last pass the rows read as zeros and are never used)
+        FD_SB();
+      });
     }
     FD_STAMP(13);
     FD_WAIT_VM(0);  // the next rows landed, the stores left (and with them the two stages in flight: once per pass)
+    commit_lo();
     FD_STAMP(14);
     ++slot;
   }
   FD_WAIT_VM(0);  // nothing may land in LDS after the workgroup has exited
 #undef FD_STAMP
+#undef FD_STAMP_G
 #undef FD_SB
 }
 
