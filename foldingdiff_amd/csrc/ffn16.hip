@@ -67,7 +67,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #ifndef FDMI_FFN_DBG
-#define FDMI_FFN_DBG 0  // ablation builds (WRONG results): 1 = no GELU arithmetic, 2 = no MFMAs of the second dense, 4 = none of the first
+#define FDMI_FFN_DBG 0  // ablation builds (WRONG results): 1 = no GELU arithmetic, 2 = no MFMAs of the second dense, 4 = none of the first,
+                        // 8 = no lo-plane fragment reads (half the LDS traffic)
 #endif
 #ifndef FDMI_FFN_PRIO
 #define FDMI_FFN_PRIO 2
@@ -248,6 +249,12 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     auto plane_reads = [&](auto S, auto LO, f16x8 (&f)[4]) __attribute__((always_inline)) {
       constexpr int s = decltype(S)::value, lo = decltype(LO)::value;
       constexpr unsigned off = (unsigned)(((s / SPS) % NST) * STAGE + (s % SPS) * STEP + lo * 1024);
+#if FDMI_FFN_DBG & 8
+      if constexpr (lo == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = fx[t];
+      } else
+#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t) f[t] = lds_f16x8(a_W + off + (unsigned)(t * TILE));
       if constexpr (lo == 0 && s < NKT) xl = lds_f16x8(a_X + (unsigned)(s * 1024));  // (the step's x_lo operand rides with its hi plane: the previous step's w_hi x_lo is done)
