@@ -57,6 +57,7 @@ struct LayerDev {
   SplitW wsa_i;  // the same q | k | v weights ordered per head for the 32-row fused projection + attention kernel (seq_attn.hip), or null
   SplitW wff_i;    // intermediate.dense + output.dense as ONE stream of ring stages (ffn16.hip), or null; scale = the first dense's
   float wff_scale_dn = 1.f;  // ... the second dense's
+  SplitW wtail_i;  // attention.output.dense's stages in front of that stream (ffn16.hip TAIL), or null; scale = attention.output.dense's
   SplitW wsa16_i;  // ... for the 16-row kernel (seq_attn16.hip: rows of a head permuted into its operand tiles), or null
   float *bqk = nullptr, *bv = nullptr;  // bias slices of bqkv
   float s_h = 1.f, s_q = 1.f, s_k = 1.f, s_v = 1.f, s_a = 1.f, s_g = 1.f;
@@ -67,11 +68,11 @@ struct LayerDev {
 
 enum KClass {
   KC_EMBED = 0, KC_GEMM_QKV, KC_GEMM_V, KC_ATTN, KC_GEMM_OUT, KC_LN1, KC_GEMM_UP, KC_GEMM_DOWN, KC_LN2, KC_GEMM_HEAD,
-  KC_HEAD_UPDATE, KC_ADVANCE, KC_SEQ_ATTN, KC_FFN, KC_COUNT
+  KC_HEAD_UPDATE, KC_ADVANCE, KC_SEQ_ATTN, KC_FFN, KC_TAIL, KC_COUNT
 };
 const char* const kClassName[KC_COUNT] = {
     "embed_ln_time", "gemm_qkv", "gemm_v", "attention", "gemm_attn_out", "layernorm_attn", "gemm_ffn_up",
-    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance", "qkv_attention_fused", "ffn_fused"};
+    "gemm_ffn_down", "layernorm_ffn", "gemm_head_dense1", "head_update_wrap", "step_advance", "qkv_attention_fused", "ffn_fused", "attn_out_ffn_fused"};
 
 struct Workspace {
   int B = 0, L = 0;
@@ -144,8 +145,8 @@ struct fd_model {
   int varlen = 0;    // row-image path: only the first lens[b] positions of a sequence are token rows
   int fuse_attn = -1;  // row-image path: q | k | v projection + attention as ONE kernel per sequence (seq_attn.hip): -1 auto (padded rows of
                      // 97 .. 128 positions), 0 never, 1 wherever the kernel applies (packed rows too)
-  int fuse_ffn = -1;   // row-image path: BertIntermediate + BertOutput as ONE kernel (ffn16.hip): -1 auto (whole rounds of 128-row passes), 0 never,
-                     // 1 wherever the kernel applies
+  int fuse_ffn = -1;   // row-image path: BertIntermediate + BertOutput as ONE kernel (ffn16.hip): -1 auto (whole rounds of 128-row passes: 2),
+                     // 0 never, 1 wherever the kernel applies, 2 with BertSelfOutput in front of it in the same launch
   // workspaces (buffers + captured graph) are kept per (B, L): sample_length()-driven sampling and ragged chunks
   // alternate between a few shapes
   std::vector<Workspace> cache;
@@ -298,7 +299,7 @@ int upload_seq_attn16_weights(fd_model* m, SplitW* dst, const float* W, int d) {
 // tiles T = 0 .. d / 16 - 1 four to a step, tile T = 2 kt + j, row i = output feature 32 kt + 8 (i / 4) + 4 j + (i % 4)).  A tile =
 // [unit 0-7][row 0-15][16 B] (units 0-3: hi of k 8 u .. 8 u + 7, 4-7: lo), a step = 8 KiB, two steps = one LDS ring stage byte for
 // byte.  Each matrix is split at its own power-of-two scale.
-int upload_ffn16_weights(fd_model* m, LayerDev* lw, const float* Wi, const float* Wd, int d, int ff) {
+int upload_ffn16_weights(fd_model* m, LayerDev* lw, const float* Wi, const float* Wd, const float* Wo, int d, int ff) {
   std::vector<uint16_t> ri, rd, img;
   pack_split_weight(Wi, ff, d, &ri, &lw->wff_i.scale, 128);
   pack_split_weight(Wd, d, ff, &rd, &lw->wff_scale_dn, 128);
@@ -330,6 +331,28 @@ int upload_ffn16_weights(fd_model* m, LayerDev* lw, const float* Wi, const float
   m->allocs.push_back(p);
   HIP_TRY(hipMemcpy(p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
   lw->wff_i.p = p;
+  if (Wo) {
+    // ... and with attention.output.dense [d][d] in front (ffn16.hip TAIL): step kt * (d / 64) + q = k32 step kt of the context against
+    // the output tiles 4 q .. 4 q + 3 (rows permuted like the second dense's)
+    std::vector<uint16_t> ro, timg;
+    pack_split_weight(Wo, d, d, &ro, &lw->wtail_i.scale, 128);
+    const int nsa = nkt * nkt / 2;
+    timg.assign((size_t)nsa * 4 * 1024 + img.size(), 0);
+    for (int kt = 0; kt < nkt; ++kt)
+      for (int T = 0; T < 2 * nkt; ++T)
+        for (int i = 0; i < 16; ++i) {
+          const int o = 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3);
+          uint16_t* tile = timg.data() + ((size_t)(kt * (nkt / 2) + T / 4) * 4 + T % 4) * 1024;
+          const uint16_t* blk = ro.data() + ((size_t)o * nkt + kt) * 64;
+          for (int u = 0; u < 8; ++u) memcpy(tile + ((size_t)u * 16 + i) * 8, blk + u * 8, 16);
+        }
+    memcpy(timg.data() + (size_t)nsa * 4 * 1024, img.data(), img.size() * 2);
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, timg.size() * 2));
+    m->allocs.push_back(q);
+    HIP_TRY(hipMemcpy(q, timg.data(), timg.size() * 2, hipMemcpyHostToDevice));
+    lw->wtail_i.p = q;
+  }
   return FD_OK;
 }
 
@@ -475,6 +498,8 @@ int ensure_ws(fd_model* m, int B, int L) {
     fl[KC_SEQ_ATTN] = 2 * Md * 3 * dd * dd + 6 * Ld * dd * Md;  by[KC_SEQ_ATTN] = 4 * (2 * Md * dd + 3 * dd * dd);
     // fused BertIntermediate + BertOutput: a in, h out, both weight matrices once (the intermediate stays on chip)
     fl[KC_FFN] = 4 * Md * ff * dd;             by[KC_FFN] = 4 * (2 * Md * dd + 2 * ff * dd);
+    // ... with BertSelfOutput in front: ctx and h in, h out, three weight matrices once
+    fl[KC_TAIL] = 4 * Md * ff * dd + 2 * Md * dd * dd;  by[KC_TAIL] = 4 * (3 * Md * dd + 2 * ff * dd + dd * dd);
   }
   w.last_use = ++m->use_clock;
   if (w.B == B && w.L == L) return FD_OK;
@@ -871,6 +896,23 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       if (!ok) return fail(FD_E_UNSUPPORTED, "attention: L=%d, head size %d", L, head_dim(c));
       DBG_STOP();
     }
+    // BertIntermediate + BertOutput as ONE kernel (ffn16.hip): the 2 d wide intermediate never reaches HBM.  fuse_ffn 2 (and auto):
+    // BertSelfOutput (attention.output.dense + residual + LayerNorm) in front of it in the same launch, its output on chip too.  Passes of 128 rows, one
+    // workgroup per CU: auto = the passes fill whole rounds of the CUs (512 passes on 256 CUs: two; 315 would leave the second round
+    // a quarter full where the tile GEMMs deal 6 + 1 column tiles per pass)
+    static const int fuse_ffn_env = [] { const char* e = getenv("FDMI_FUSE_FFN"); return e ? atoi(e) : -1; }();
+    const int fuse_ffn = m->fuse_ffn >= 0 ? m->fuse_ffn : fuse_ffn_env;
+    bool ffn_auto = false;
+    {
+      const int ncu = gemm_img_grid(1 << 30, 384), passes = max_rows / 128;
+      const int rounds = (passes + ncu - 1) / ncu;
+      ffn_auto = (double)passes >= 0.94 * (double)rounds * ncu;
+    }
+    const bool fused_ffn_any = fuse_ffn != 0 && (fuse_ffn > 0 || ffn_auto) && lw.wff_i.p && ffn16_supported(d, ff) &&
+                           (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
+    const bool fused_ffn = fused_ffn_any;
+    const bool fused_tail = fused_ffn && fuse_ffn != 1 && lw.wtail_i.p && d <= 384;
+    if (!fused_tail)
     {
       GemmImgArgs g = base();
       g.A = w.cimg; g.W = static_cast<const unsigned char*>(lw.wo_i.p); g.bias = lw.bo; g.gamma = lw.ln1g; g.beta = lw.ln1b;
@@ -887,24 +929,15 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       }
       DBG_STOP();
     }
-    // BertIntermediate + BertOutput as ONE kernel (ffn16.hip): the 2 d wide intermediate never reaches HBM.  Passes of 128 rows, one
-    // workgroup per CU: auto = the passes fill whole rounds of the CUs (512 passes on 256 CUs: two; 315 would leave the second round
-    // a quarter full where the tile GEMMs deal 6 + 1 column tiles per pass)
-    static const int fuse_ffn_env = [] { const char* e = getenv("FDMI_FUSE_FFN"); return e ? atoi(e) : -1; }();
-    const int fuse_ffn = m->fuse_ffn >= 0 ? m->fuse_ffn : fuse_ffn_env;
-    bool ffn_auto = false;
-    {
-      const int ncu = gemm_img_grid(1 << 30, 384), passes = max_rows / 128;
-      const int rounds = (passes + ncu - 1) / ncu;
-      ffn_auto = (double)passes >= 0.94 * (double)rounds * ncu;
-    }
-    const bool fused_ffn = fuse_ffn != 0 && (fuse_ffn > 0 || ffn_auto) && lw.wff_i.p && ffn16_supported(d, ff) &&
-                           (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
     if (fused_ffn) {
       FfnArgs a;
       memset(&a, 0, sizeof a);
       a.aimg = w.aimg; a.a_bytes = (unsigned)((size_t)w.cap * d * 4);
-      a.wimg = static_cast<const unsigned char*>(lw.wff_i.p);
+      a.wimg = static_cast<const unsigned char*>(fused_tail ? lw.wtail_i.p : lw.wff_i.p);
+      if (fused_tail) {
+        a.cimg = w.cimg; a.hres = w.himg; a.bo = lw.bo; a.g1 = lw.ln1g; a.b1 = lw.ln1b;
+        a.ao_scale = 1.0f / (lw.s_v * lw.wtail_i.scale); a.hres_inv = 1.0f / lw.s_h; a.a_scale = lw.s_a; a.eps1 = c.ln_eps;
+      }
       a.bi = lw.bi; a.bd = lw.bd; a.gamma = lw.ln2g; a.beta = lw.ln2b;
       a.out = w.himg; a.out_bytes = a.a_bytes;
       a.panels = max_rows / 128;
@@ -912,10 +945,12 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       a.resid_inv = 1.0f / lw.s_a; a.out_scale = s_next; a.eps = c.ln_eps;
       a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16 + 16384 : nullptr;
       bool launched = false;
-      PROF(KC_FFN, launched = launch_ffn16(a, d, s));
+      if (fused_tail) PROF(KC_TAIL, launched = launch_ffn16(a, d, s));
+      else PROF(KC_FFN, launched = launch_ffn16(a, d, s));
       if (!launched) return fail(FD_E_HIP, "the fused feed-forward kernel could not be launched");
+      if (fused_tail) DBG_STOP();
       DBG_STOP();
-      DBG_STOP();  // (two launches of the other path: debug_stop counts stay comparable)
+      DBG_STOP();  // (two / three launches of the other path: debug_stop counts stay comparable)
       continue;
     }
     {
@@ -1424,8 +1459,9 @@ int fd_finalize(fd_model* m, int T, const float* coef, const float* time_table, 
       if (int rc = upload_split(m, &lw.wi_i, wi->data.data(), (int)ff, (int)d, 384)) return rc;
       if (int rc = upload_split(m, &lw.wd_i, wd->data.data(), (int)d, (int)ff, 384)) return rc;
       lw.wff_i = SplitW();
+      lw.wtail_i = SplitW();
       if (ffn16_supported((int)d, (int)ff))
-        if (int rc = upload_ffn16_weights(m, &lw, wi->data.data(), wd->data.data(), (int)d, (int)ff)) return rc;
+        if (int rc = upload_ffn16_weights(m, &lw, wi->data.data(), wd->data.data(), wo->data.data(), (int)d, (int)ff)) return rc;
       const Bound ab = ln_bound(g1, b1);
       lw.s_a = scale_for(ab.linf);
       lw.s_g = scale_for(dense_bound(wi->data.data(), bi->data.data(), 0, (int)ff, (int)d, ab.l2));  // |gelu(u)| <= |u|
@@ -1486,7 +1522,7 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   else if (n == "use_graph") m->use_graph = value ? 1 : 0;
   else if (n == "varlen") m->varlen = value ? 1 : 0;
   else if (n == "fuse_attn") m->fuse_attn = value < 0 ? -1 : (value > 2 ? 1 : value);
-  else if (n == "fuse_ffn") m->fuse_ffn = value < 0 ? -1 : (value ? 1 : 0);
+  else if (n == "fuse_ffn") m->fuse_ffn = value < 0 ? -1 : (value > 2 ? 2 : value);
   else if (n == "split_qkv") {
     m->split_qkv = value ? 1 : 0;
     drop_workspaces(m);  // captured graphs hold the other launch sequence

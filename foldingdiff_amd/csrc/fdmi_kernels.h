@@ -215,6 +215,17 @@ struct FfnArgs {
   float resid_inv;             // 1 / scale of aimg
   float out_scale;             // scale of the output image
   float eps;
+  // the layer's tail in one launch: cimg != null -> BertSelfOutput (attention.output.dense + residual + LayerNorm) runs in front, on the
+  // attention context; aimg is then unused (its rows never reach HBM) and wimg starts with attention.output.dense's stages
+  const unsigned char* cimg;   // attention context image [rows128][d/32], a_bytes long
+  const unsigned char* hres;   // the layer's input rows (residual of BertSelfOutput), a_bytes long; may alias out (a row is read, then written, by one wave)
+  const float* bo;             // [d]  attention.output.dense.bias
+  const float* g1;             // [d]  attention.output.LayerNorm
+  const float* b1;
+  float ao_scale;              // 1 / (scale of cimg * scale of attention.output.dense's weights)
+  float hres_inv;              // 1 / scale of hres
+  float a_scale;               // scale of BertSelfOutput's output images (= 1 / resid_inv)
+  float eps1;
   unsigned long long* stamps;  // null, or [8 waves][16 passes][16] cycle stamps of workgroup 0 (debug)
 };
 bool ffn16_supported(int d_model, int d_ff);

@@ -91,7 +91,10 @@ __host__ __device__ constexpr int off_p(int nkt) { return OFF_X + NW * nkt * 102
 
 // PROF: workgroup 0 records s_memtime stamps (FDMI_STAMPS=1): stamps[wave][pass, 16][16] = 0 pass top | 1..12 after group G | 13 after
 // the LayerNorm and its stores | 14 after the next rows landed
-template <int NKT, bool PROF>
+// TAIL: BertSelfOutput (attention.output.dense + residual + LayerNorm) runs in front, on the attention context; its output never
+// reaches HBM either: in the C/D layout of the swapped form it IS the stationary B operand of the first dense (the same lanes hold the
+// same eight features) -- the hi halves go to the registers the context's hi plane occupied, the lo halves to its LDS rows.
+template <int NKT, bool TAIL, bool PROF>
 __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
   static_assert(NKT == 12 || NKT == 6, "d_model 384 or 192, intermediate size 2 d_model");
   constexpr int D = 32 * NKT;          // d_model
@@ -99,8 +102,11 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
   constexpr int SPG = 2 * NKT;         // steps per group: NKT of the first dense (k32 steps), NKT of the second (2 pairs x 2 NKT tiles / 4)
   constexpr int STG = SPG / SPS;       // stages per group
   static_assert(STG % NST == 0, "a group is a whole number of ring turns: its first stage always sits in slot 0");
-  constexpr int W_BYTES = NG * STG * STAGE;
+  constexpr int NSA = TAIL ? NKT * NKT / 2 : 0;  // steps of attention.output.dense: k32 step kt = s / (NKT / 2), output tiles 4 q .. 4 q + 3
+  static_assert((NSA / SPS) % NST == 0 && NSA % SPS == 0, "whole ring turns");
+  constexpr int W_BYTES = (NSA / SPS + NG * STG) * STAGE;
   constexpr int OFF_P = off_p(NKT);
+  constexpr int OFF_P1 = OFF_P + 5 * D * 4;    // TAIL: b_o / os [d] | gamma_1 [d] | beta_1 at the scale of its image [d]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,6 +128,11 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
       par[2 * D + i] = p.bd[i];
       par[3 * D + i] = p.gamma[i];
       par[4 * D + i] = p.beta[i] * p.out_scale;  // (a power of two: exact)
+      if constexpr (TAIL) {
+        par[5 * D + i] = p.bo[i] * (1.0f / p.ao_scale);  // (1 / os = the product of two image scales, a power of two)
+        par[6 * D + i] = p.g1[i];
+        par[7 * D + i] = p.b1[i] * p.a_scale;
+      }
     }
   }
 
@@ -141,7 +152,9 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
   // ---- the wave's sixteen rows of the input image: k32 step kt, lane (c, g): row c, features 32 kt + 8 g .. + 7; the hi plane in
   // registers, the lo plane in this wave's 12 KiB of LDS ([kt][lane][16 B]: nobody else touches them, no barrier involved)
   f16x8 ah[NKT];
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.aimg), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(TAIL ? p.cimg : p.aimg), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(TAIL ? p.hres : p.aimg), 0, p.a_bytes, 0x00020000);
   auto row_off = [&](int r0) __attribute__((always_inline)) {
     const int ln = lane_id();
     const int row = r0 + 16 * wq + (ln & 15);
@@ -168,6 +181,14 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     for (int kt = 0; kt < NKT; ++kt) *(__attribute__((address_space(3))) u32x4*)(unsigned long long)(ax + (unsigned)(kt * 1024)) = tl[kt];
   };
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  // TAIL: the residual of BertSelfOutput (the layer's input rows) is loaded straight into the accumulators of attention.output.dense
+  // -- raw hi / lo words first (tile 2 kt: hi, 2 kt + 1: lo), turned into (b_o + h) / os at the pass top: os is a power of two, so the
+  // accumulators then simply start from the bias and the residual instead of zero
+  auto load_res = [&](auto KT, unsigned hoff, f32x4 (&Yr)[2 * NKT]) __attribute__((always_inline)) {
+    constexpr int kt = decltype(KT)::value;
+    Yr[2 * kt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, (int)hoff, kt * 8 * 512, 0));
+    Yr[2 * kt + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, (int)hoff, (kt * 8 + 4) * 512, 0));
+  };
 
   const bool rec = PROF && blockIdx.x == 0 && p.stamps != nullptr;
   unsigned long long* stp = PROF ? p.stamps + (size_t)wq * 16 * 16 : nullptr;
@@ -190,6 +211,7 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
   {
     const unsigned hoff = row_off((int)blockIdx.x * 128);
     static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) { load_lo(KT, hoff); });
+    if constexpr (TAIL) static_for<0, NKT>([&](auto KT) __attribute__((always_inline)) { load_res(KT, hoff, Y); });
   }
   issue_w();
   issue_w();
@@ -226,9 +248,11 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     ul[pr][j] = c;
   };
 
+  // GEL = 2: the steps of attention.output.dense (TAIL): k32 step kt = s / (NKT / 2) of the context (B operand), output tiles
+  // 4 q .. 4 q + 3, q = s % (NKT / 2)
   auto steps = [&](auto S0, auto S1, auto GEL, unsigned abq) __attribute__((always_inline)) {
     constexpr int s0 = decltype(S0)::value, s1 = decltype(S1)::value;
-    constexpr bool gel = decltype(GEL)::value != 0;
+    constexpr bool gel = decltype(GEL)::value == 1, pha = decltype(GEL)::value == 2;
     auto stage_top = [&]() __attribute__((always_inline)) {
 #ifdef FDMI_FFN_SAFE  // debug build: no counted wait
       FD_WAIT_VM(0);
@@ -257,12 +281,21 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
 #endif
 #pragma unroll
       for (int t = 0; t < 4; ++t) f[t] = lds_f16x8(a_W + off + (unsigned)(t * TILE));
-      if constexpr (lo == 0 && s < NKT) xl = lds_f16x8(a_X + (unsigned)(s * 1024));  // (the step's x_lo operand rides with its hi plane: the previous step's w_hi x_lo is done)
+      // (the step's x_lo operand rides with its hi plane: the previous step's w_hi x_lo is done)
+      if constexpr (pha) {
+        if constexpr (lo == 0 && s % (NKT / 2) == 0) xl = lds_f16x8(a_X + (unsigned)((s / (NKT / 2)) * 1024));
+      } else {
+        if constexpr (lo == 0 && s < NKT) xl = lds_f16x8(a_X + (unsigned)(s * 1024));
+      }
     };
     // which: 0 = w_hi x_hi, 1 = w_hi x_lo, 2 = w_lo x_hi; consecutive MFMAs never share an accumulator
     auto mm = [&](auto S, auto WHICH, const f16x8 (&f)[4]) __attribute__((always_inline)) {
       constexpr int s = decltype(S)::value, which = decltype(WHICH)::value;
-      if constexpr (s < NKT) {
+      if constexpr (pha) {
+        constexpr int kt = s / (NKT / 2), q = s % (NKT / 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Y[4 * q + t] = mfma16(f[t], which == 1 ? xl : ah[kt], Y[4 * q + t]);
+      } else if constexpr (s < NKT) {
 #if !(FDMI_FFN_DBG & 4)
 #pragma unroll
         for (int t = 0; t < 4; ++t) U[t] = mfma16(f[t], which == 1 ? xl : ah[s], U[t]);
@@ -343,6 +376,78 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
 
   for (int panel = blockIdx.x; panel < p.panels; panel += (int)gridDim.x) {
     FD_STAMP(0);
+    if constexpr (TAIL) {
+      // ================================================ BertSelfOutput: dense on the context + bias + residual, LayerNorm
+      const int ln = lane_id();
+      const int g = ln >> 4;
+      const unsigned pb1 = smem0 + OFF_P1 + (unsigned)(8 * g * 4);
+      const unsigned ax = smem0 + OFF_X + (unsigned)(wq * NKT * 1024 + ln * 16);
+      {
+        const float c = p.hres_inv * (1.0f / p.ao_scale);  // (both powers of two)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const u32x4 rh = __builtin_bit_cast(u32x4, Y[2 * kt]), rl = __builtin_bit_cast(u32x4, Y[2 * kt + 1]);
+          const u32x4 b0 = lds_u128(pb1 + (unsigned)(kt * 128)), b1 = lds_u128(pb1 + (unsigned)(kt * 128 + 16));
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const unsigned hw = rh[2 * j + e / 2], lw = rl[2 * j + e / 2];  // features 8 g + 4 j + e, + 1 of block kt
+              const unsigned bw0 = j == 0 ? b0[e] : b1[e], bw1 = j == 0 ? b0[e + 1] : b1[e + 1];
+              float v0 = fma_mix_lo(hw, c, __builtin_bit_cast(float, bw0));
+              float v1 = fma_mix_hi(hw, c, __builtin_bit_cast(float, bw1));
+              Y[2 * kt + j][e] = fma_mix_lo(lw, c, v0);
+              Y[2 * kt + j][e + 1] = fma_mix_hi(lw, c, v1);
+            }
+        }
+      }
+      steps(IC<0>{}, IC<NSA>{}, IC<2>{}, 0u);
+      // LayerNorm; its output at the scale of the image the two-kernel path writes (s_a): hi halves -> the stationary B operand,
+      // lo halves -> this wave's LDS rows (the context's planes are dead)
+      const float os_ao = p.ao_scale;
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2 * NKT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Y[t][e] *= os_ao;
+          sum += Y[t][e];
+        }
+      const float inv_n = 1.0f / (float)D;
+      float mean = quad_sum(sum) * inv_n;
+      asm volatile("" : "+v"(mean));
+      float t2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2 * NKT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dl = Y[t][e] - mean;
+          Y[t][e] = dl;
+          t2 = __builtin_fmaf(dl, dl, t2);
+        }
+      const float rstd = (1.0f / sqrtf(__builtin_fmaf(quad_sum(t2), inv_n, p.eps1))) * p.a_scale;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const u32x4 g0 = lds_u128(pb1 + (unsigned)(D * 4 + kt * 128)), g1 = lds_u128(pb1 + (unsigned)(D * 4 + kt * 128 + 16));
+        const u32x4 e0 = lds_u128(pb1 + (unsigned)(2 * D * 4 + kt * 128)), e1 = lds_u128(pb1 + (unsigned)(2 * D * 4 + kt * 128 + 16));
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = __builtin_fmaf(Y[2 * kt][e] * rstd, __builtin_bit_cast(float, (unsigned)g0[e]), __builtin_bit_cast(float, (unsigned)e0[e]));
+          o[4 + e] = __builtin_fmaf(Y[2 * kt + 1][e] * rstd, __builtin_bit_cast(float, (unsigned)g1[e]), __builtin_bit_cast(float, (unsigned)e1[e]));
+        }
+        u32x4 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned a, b;
+          split_pair(o[2 * j], o[2 * j + 1], a, b);
+          hv[j] = a;
+          lv[j] = b;
+        }
+        ah[kt] = __builtin_bit_cast(f16x8, hv);
+        *(__attribute__((address_space(3))) u32x4*)(unsigned long long)(ax + (unsigned)(kt * 1024)) = lv;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 2 * NKT; ++t) Y[t] = zero4;
     // Software pipeline over the groups: the first dense of group G + 1 runs BEFORE the second dense of group G, and the GELU of group G
@@ -446,6 +551,7 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
         __builtin_amdgcn_raw_buffer_store_b128(hv, rs_o, (int)ooff, kt * 8 * 512, 0);
         __builtin_amdgcn_raw_buffer_store_b128(lv, rs_o, (int)ooff, (kt * 8 + 4) * 512, 0);
         load_lo(KT, noff);  // (unconditionally: beyond the last pass the rows read as zeros and are never used)
+        if constexpr (TAIL) load_res(KT, noff, Y);
         FD_SB();
       });
     }
@@ -471,16 +577,16 @@ static int n_cu_of(int dev) {
   return cached[dev];
 }
 
-template <int NKT>
+template <int NKT, bool TAIL>
 static bool launch(const FfnArgs& p, hipStream_t s) {
-  constexpr int SMEM = off_p(NKT) + 5 * 32 * NKT * 4;
+  constexpr int SMEM = off_p(NKT) + (TAIL ? 8 : 5) * 32 * NKT * 4;
   static int attr_state[64] = {0};  // 0 unknown, 1 set, -1 refused
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   if (attr_state[dev] == 0) {
     bool ok = true;
-    for (const void* f : {reinterpret_cast<const void*>(&ffn16_kernel<NKT, false>), reinterpret_cast<const void*>(&ffn16_kernel<NKT, true>)})
+    for (const void* f : {reinterpret_cast<const void*>(&ffn16_kernel<NKT, TAIL, false>), reinterpret_cast<const void*>(&ffn16_kernel<NKT, TAIL, true>)})
       ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
     attr_state[dev] = ok ? 1 : -1;
   }
@@ -488,8 +594,8 @@ static bool launch(const FfnArgs& p, hipStream_t s) {
   int grid = n_cu_of(dev);
   if (grid > p.panels) grid = p.panels;
   if (grid <= 0) return true;
-  if (p.stamps) hipLaunchKernelGGL((ffn16_kernel<NKT, true>), dim3(grid), dim3(64 * NW), SMEM, s, p);
-  else hipLaunchKernelGGL((ffn16_kernel<NKT, false>), dim3(grid), dim3(64 * NW), SMEM, s, p);
+  if (p.stamps) hipLaunchKernelGGL((ffn16_kernel<NKT, TAIL, true>), dim3(grid), dim3(64 * NW), SMEM, s, p);
+  else hipLaunchKernelGGL((ffn16_kernel<NKT, TAIL, false>), dim3(grid), dim3(64 * NW), SMEM, s, p);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -498,6 +604,9 @@ static bool launch(const FfnArgs& p, hipStream_t s) {
 // d_model 384 / 192 (every released configuration / the reference's test fixture) with the intermediate size 2 d_model they all have
 bool ffn16_supported(int d_model, int d_ff) { return (d_model == 384 || d_model == 192) && d_ff == 2 * d_model; }
 
-bool launch_ffn16(const FfnArgs& p, int d_model, hipStream_t s) { return d_model == 384 ? ffn::launch<12>(p, s) : ffn::launch<6>(p, s); }
+bool launch_ffn16(const FfnArgs& p, int d_model, hipStream_t s) {
+  if (p.cimg) return d_model == 384 ? ffn::launch<12, true>(p, s) : ffn::launch<6, true>(p, s);
+  return d_model == 384 ? ffn::launch<12, false>(p, s) : ffn::launch<6, false>(p, s);
+}
 
 }  // namespace fdmi

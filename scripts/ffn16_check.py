@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The fused feed-forward kernel (ffn16.hip, fuse_ffn = 1: BertIntermediate + GELU + BertOutput in one launch) against the oracle, next
-to the two-GEMM path (0): released shape and the mini shape, L from 7 to 128, ragged lengths, padded and packed rows, with the fused
+"""The fused feed-forward kernel (ffn16.hip; fuse_ffn = 1: BertIntermediate + GELU + BertOutput in one launch, 2: BertSelfOutput in front
+of them too) against the oracle, next to the GEMM path (0): released shape and the mini shape, L from 7 to 128, ragged lengths, padded and packed rows, with the fused
 attention kernel on and off.  Gate: max|d| <= 1e-5 against the fp32 oracle on valid positions (tests/test_gpu_parity.py: FWD_TOL)."""
 import os
 import sys
@@ -49,9 +49,9 @@ for cf in CASES:
     for packed in (0, 1):
         pm.set_option("varlen", packed)
         outs = {}
-        for fa in (0, 1, 2):
-            pm.set_option("fuse_attn", 1 if fa == 2 else 0)
-            pm.set_option("fuse_ffn", 1 if fa else 0)
+        for fa in (0, 1, 2, 3):
+            pm.set_option("fuse_attn", 1 if fa == 3 else 0)
+            pm.set_option("fuse_ffn", (0, 1, 2, 2)[fa])
             try:
                 outs[fa] = pm(x, t, attention_mask=mask).detach().cpu()
             except _binding.FdmiError as e:
@@ -60,10 +60,10 @@ for cf in CASES:
         ref = want if want is not None else outs[0]
         errs = {fa: float((o[sel] - ref[sel]).abs().max()) for fa, o in outs.items()}
         nan = {fa: int(torch.isnan(o[sel]).sum()) for fa, o in outs.items()}
-        ok = all(errs.get(k, 1.0) <= (1e-5 if want is not None else 2e-5) and nan.get(k, 1) == 0 for k in (1, 2))
+        ok = all(errs.get(k, 1.0) <= (1e-5 if want is not None else 2e-5) and nan.get(k, 1) == 0 for k in (1, 2, 3))
         bad += 0 if ok else 1
         print(f"d={d} layers={nl} B={B} L={L} packed={packed}: max|d| vs {'oracle' if want is not None else 'two-kernel'}: "
-              + "  ".join(f"{('two GEMMs', 'ffn16', 'ffn16 + seq_attn16')[fa]}: {e:.3e}" + (f" ({nan[fa]} NaN)" if nan[fa] else "") for fa, e in errs.items())
+              + "  ".join(f"{('three GEMMs', 'ffn16', 'tail', 'tail + seq_attn16')[fa]}: {e:.3e}" + (f" ({nan[fa]} NaN)" if nan[fa] else "") for fa, e in errs.items())
               + f"   {'OK' if ok else 'FAIL'}", flush=True)
         if not ok and want is not None and os.environ.get("VERBOSE"):
             dd = (outs[1] - ref).abs()

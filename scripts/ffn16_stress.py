@@ -27,7 +27,7 @@ t = torch.full((B,), 42, dtype=torch.long)
 pm.set_option("fuse_attn", 0)
 pm.set_option("fuse_ffn", 0)
 ref = pm(x, t, attention_mask=mask).detach().cpu()
-pm.set_option("fuse_ffn", 1)
+pm.set_option("fuse_ffn", int(os.environ.get("FUSE_FFN", 2)))
 bad = 0
 worst = 0.0
 for it in range(int(os.environ.get("N", 40))):
