@@ -126,6 +126,61 @@ def cpu_baseline(B, L, T, shape, steps=10, check_batch=8):
     }
 
 
+class PowerClockSampler:
+    """Socket power and shader clock of THIS process's GPU (hwmon files of the card with the device's PCI bus id) sampled every ~10 ms
+    while the timed region runs: the path is power-limited (profiles/r06_power_probe.log), so the clock belongs next to the time."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.rows, self.on, self.src = [], False, {}
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if want not in os.path.realpath(card):
+                    continue
+                for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                    for name in ("power1_average", "power1_input", "freq1_input", "power1_cap"):
+                        if os.path.exists(os.path.join(hw, name)):
+                            self.src[name] = os.path.join(hw, name)
+                break
+        except Exception:  # noqa: BLE001  (telemetry only)
+            self.src = {}
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        try:
+            with open(self.src[name]) as fh:
+                return float(fh.read().strip())
+        except Exception:  # noqa: BLE001
+            return float("nan")
+
+    def _run(self):
+        pw = "power1_average" if "power1_average" in self.src else "power1_input"
+        while self.on:
+            self.rows.append((self._read(pw) / 1e6, self._read("freq1_input") / 1e6))
+            time.sleep(0.01)
+
+    def start(self):
+        if "freq1_input" in self.src:
+            self.on = True
+            self.thread.start()
+
+    def stop(self):
+        if not self.on:
+            return None
+        self.on = False
+        self.thread.join(timeout=1.0)
+        a = np.array(self.rows[len(self.rows) // 5:], dtype=float)   # (the first fifth: clocks still settling)
+        if not len(a):
+            return None
+        med = lambda v: float(np.nanmedian(v))   # noqa: E731
+        return {"sclk_mhz_median": round(med(a[:, 1])), "socket_power_w_median": round(med(a[:, 0])),
+                "power_cap_w": round(self._read("power1_cap") / 1e6) if "power1_cap" in self.src else None, "samples": int(len(a)),
+                "note": "hwmon of this GPU sampled every 10 ms inside the timed region; the shader clock's ceiling is 2400 MHz"}
+
+
 def measure_traffic(kernel_substr, args):
     """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need separate
     passes: MI355X_MICROARCH.md, TCC counter slots) over a 3-timestep eager run of this script, counters of the launches whose kernel
@@ -267,12 +322,16 @@ def main():
     sync_all()
     _binding.check(lib.fd_profile_reset(h))
     _binding.check(lib.fd_profile_every(h, args.profile_every))
+    sampler = PowerClockSampler(local_rank if world > 1 else 0) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     last = None
     for k in range(args.steps):
         last = one_pass(k)
     sync_all()
     elapsed = time.perf_counter() - t0
+    telemetry = sampler.stop() if sampler else None
     _binding.check(lib.fd_profile_every(h, 0))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -308,21 +367,32 @@ def main():
     hbm_bytes_step = sum(v["bytes"] * per_step_launches.get(k, RELEASED["num_hidden_layers"]) for k, v in kernels.items())
     mfma_mult = 3.0 if model.precision == "f16x3" else 1.0
     ms_step = elapsed / args.steps / T * 1e3
-    # the dominant launch: the fused q|k|v projection + attention kernel (seq_attn.hip) where it runs, else the q|k|v GEMM
-    dom_name = "qkv_attention_fused" if "qkv_attention_fused" in kernels else "gemm_qkv"
+    # the dominant launch: the per-layer kernel with the most time per timestep (round 6: the layer's tail in one launch, ffn16.hip;
+    # before it the fused q|k|v projection + attention kernel)
+    per_layer = {k: v for k, v in kernels.items() if k not in per_step_launches}
+    dom_name = max(per_layer, key=lambda k: per_layer[k]["avg_ms"]) if per_layer else "gemm_qkv"
     dom = kernels.get(dom_name)
     pinfo_key = model.precision  # (the exact-fp32 pass below switches the model)
     pinfo = PRECISION_INFO[pinfo_key]
     legacy_fused = os.environ.get("FDMI_FUSE_ATTN") == "2"
     dom_kernel = pinfo["kernel"]
-    if dom_name == "qkv_attention_fused":
-        dom_kernel = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_32x32x16_f16 per product)" if legacy_fused else
-                      "s16::seq_attn16_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, 16-row waves, "
-                      "two per SIMD, fp16 hi/lo split, 3x v_mfma_f32_16x16x32_f16 per product)")
+    sa_desc = ("sa::seq_attn_kernel<12> (round 5: 32-row waves, one per SIMD, 3x v_mfma_f32_32x32x16_f16 per product)" if legacy_fused else
+               "s16::seq_attn16_kernel<12> (q|k|v projection + relative_key attention of a whole sequence per workgroup, 16-row waves, "
+               "two per SIMD, fp16 hi/lo split, 3x v_mfma_f32_16x16x32_f16 per product)")
+    KDESC = {
+        "attn_out_ffn_fused": ("ffn16_kernel", "ffn::ffn16_kernel<12, true> (the layer's tail in one launch: attention.output.dense + residual + "
+                               "LayerNorm + intermediate.dense + GELU + output.dense + residual + LayerNorm of 128 rows per pass, 16-row waves, two per "
+                               "SIMD, fp16 hi/lo split, 3x v_mfma_f32_16x16x32_f16 per product)"),
+        "ffn_fused": ("ffn16_kernel", "ffn::ffn16_kernel<12, false> (intermediate.dense + GELU + output.dense + residual + LayerNorm of 128 rows "
+                      "per pass, 16-row waves, 3x v_mfma_f32_16x16x32_f16 per product)"),
+        "qkv_attention_fused": ("seq_attn", sa_desc),
+    }
+    sub = "gemm_img_kernel<5" if model.precision == "f16x3" else "gemm_f32_kernel"
+    if dom_name in KDESC:
+        sub, dom_kernel = KDESC[dom_name]
     traffic, traffic_note = None, "not measured (--no-traffic, N > 1 or another shape)"
     if world == 1 and not args.no_traffic and (B, L) == (512, 128) and dom:
-        traffic, traffic_note = measure_traffic("seq_attn" if dom_name == "qkv_attention_fused" else
-                                                ("gemm_img_kernel<5" if model.precision == "f16x3" else "gemm_f32_kernel"), args)
+        traffic, traffic_note = measure_traffic(sub, args)
     roofline = None
     if dom:
         roofline = {
@@ -332,7 +402,12 @@ def main():
             "traffic_source": traffic_note,
             "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "flops_per_launch": dom["flops"],
             "algorithmic_bytes_per_launch": dom["bytes"],
+            "profile_name": dom_name,
         }
+    # the other fused kernel of a layer, priced the same way (no counter pass)
+    roofline_others = [{"profile_name": k, "kernel": KDESC[k][1], "bound": "mfma", "achieved": v["tflops"], "peak": pinfo["peak"],
+                        "unit": "TFLOP/s", "frac": v["tflops"] / pinfo["peak"], "avg_launch_ms": v["avg_ms"], "launches_timed": v["launches"]}
+                       for k, v in per_layer.items() if k != dom_name and k in KDESC]
     result = {
         "metric": f"backbones/sec (L={L}, T={T}, bs={B})",
         "value": value,
@@ -365,9 +440,12 @@ def main():
                                "used (3 MFMAs per product in f16x3; a dense MFMA stream on random operands clocks the chip at ~1.6 GHz, "
                                "profiles/r03_clock_probe.log, so the sustained matrix peak is ~2/3 of the 2.4 GHz figure).  Neither floor shows what "
                                "the probes measured (profiles/r04_ingest_probe.log): a GEMM tile takes loaded bytes / 35 B/clk + STORED bytes / "
-                               "9.4 B/clk per CU, not overlapping -- the path writes 9.7 GB of activations per timestep at the chip's 4.6 TB/s "
-                               "write rate (~2.1 ms) with the loads and the matrix pipe waiting"},
+                               "9.4 B/clk per CU, not overlapping; with the two fused kernels of a layer (seq_attn16.hip, ffn16.hip) an activation row "
+                               "leaves the chip twice per layer (ctx, h) instead of seven times.  The loop runs at the 1400 W socket power cap with "
+                               "the shader clock well below 2.4 GHz (`clocks`; profiles/r06_power_probe.log)"},
         "roofline": roofline,
+        "roofline_others": roofline_others,
+        "clocks": telemetry,
         "kernels": {k: {"avg_ms": round(v["avg_ms"], 5), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
                         "launches": v["launches"]} for k, v in kernels.items()},
         # the HBM-bound row kernels north_star singles out: algorithmic bytes / measured launch time against the 8 TB/s peak

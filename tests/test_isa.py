@@ -298,3 +298,46 @@ def test_sixteen_row_fused_attention_kernel_is_spill_free_and_keeps_its_weight_s
     for m in re.finditer(r"\.name:\s+_ZN4fdmi3s1617seq_attn16_kernelILi(\d+)ELb0EEEvNS_11SeqAttnArgsE\n(.*?)\.wavefront_size", asm, re.S):
         fields = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(2))}
         assert fields["private_segment_fixed_size"] == 0 and fields["vgpr_spill_count"] == 0 and fields["vgpr_count"] <= 256, fields
+
+
+# ------------------------------------------------------------ ffn16.hip (round 6)
+def test_fused_layer_tail_kernel_is_spill_free_and_keeps_its_weight_stream_counted(tmp_path):
+    """ffn::ffn16_kernel (d_model 384 and 192; with and without BertSelfOutput in front): two waves per SIMD, <= 256 registers each
+    (96 output accumulators + 48 of the stationary operand).  With both planes of the stationary operand in registers hipcc spilled
+    the image and reloaded it behind vmcnt(0) in every group (profiles/r06_ffn16_notes.log): pinned -- no scratch, only the
+    hand-written vector-memory waits (counted: 2 = the pieces of the next stage, 4 / 6 in the prologue; vmcnt(0) in the parameter
+    fill, at a pass's end and the kernel's), every contraction on v_mfma_f32_16x16x32_f16 and as many of them as the arithmetic needs
+    (3 per 16 x 16 x 32 tile product), no packed fp32 arithmetic beside the partner wave's matrix instructions, no LDS-DMA into the
+    rows' lo plane (it arrived stale: the plane goes through registers)."""
+    try:
+        hipcc = fbuild.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    out = tmp_path / "ffn16.s"
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={fbuild.ARCH}", "-I", os.path.join(REPO, "include")] \
+        + fbuild.PER_SOURCE_FLAGS.get("ffn16", []) + ["-S", "--cuda-device-only", "-o", str(out), os.path.join(fbuild.CSRC, "ffn16.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert wide_store_hazards(asm) == []
+    found = 0
+    for m in re.finditer(r"^(_ZN4fdmi3ffn12ffn16_kernelILi(\d+)ELb([01])ELb0EEEvNS_7FfnArgsE):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
+        nkt, tail, body = int(m.group(2)), int(m.group(3)), m.group(4)
+        found += 1
+        assert "scratch_" not in body, (nkt, tail)
+        assert "v_accvgpr" not in body, (nkt, tail)
+        assert not re.search(r"v_pk_(fma|mul|add)_f32", body), (nkt, tail)
+        # per pass: the first group's first dense once, the loop body (next group's first dense + this group's second) once, the last
+        # group's second dense once: 3 x NKT steps of 12 MFMAs; TAIL: + NKT * NKT / 2 steps
+        steps = 3 * nkt + (nkt * nkt // 2 if tail else 0)
+        assert "v_mfma_f32_32x32" not in body and body.count("v_mfma_f32_16x16x32_f16") == 12 * steps, (nkt, tail)
+        waits = [int(x) for x in re.findall(r"s_waitcnt\s+vmcnt\((\d+)\)", body)]
+        # (everything but the stage tops' vmcnt(2): the parameter fill in front of the first barrier, the prologue, a pass's end, the kernel's)
+        assert set(waits) <= {0, 1, 2, 3, 4, 5, 6}, (nkt, tail, sorted(set(waits)))
+        assert waits.count(0) <= 5 and sum(1 for w in waits if w != 2) <= 12, (nkt, tail, waits)
+        assert body.count("s_barrier") == 2 * (steps // 2) + 1, (nkt, tail)   # a stage top per two steps, at one of two places per wave group
+        assert body.count("offen lds") == 3 * 2 + 2 * 2 * (steps // 2), (nkt, tail)   # the weight stream's pieces only
+    assert found == 4
+    for m in re.finditer(r"\.name:\s+_ZN4fdmi3ffn12ffn16_kernelILi(\d+)ELb[01]ELb0EEEvNS_7FfnArgsE\n(.*?)\.wavefront_size", asm, re.S):
+        fields = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(2))}
+        assert fields["private_segment_fixed_size"] == 0 and fields["vgpr_spill_count"] == 0 and fields["vgpr_count"] <= 256, fields
