@@ -940,7 +940,7 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       }
       a.bi = lw.bi; a.bd = lw.bd; a.gamma = lw.ln2g; a.beta = lw.ln2b;
       a.out = w.himg; a.out_bytes = a.a_bytes;
-      a.panels = max_rows / 128;
+      a.panels = max_rows / 128; a.dims = w.dims;
       a.up_scale = 1.0f / (lw.s_a * lw.wff_i.scale); a.g_scale = lw.s_g; a.down_scale = 1.0f / (lw.s_g * lw.wff_scale_dn);
       a.resid_inv = 1.0f / lw.s_a; a.out_scale = s_next; a.eps = c.ln_eps;
       a.stamps = m->stamps ? m->stamps + 5 * 8 * 64 * 6 + 4 * 64 * 8 + 4 * 64 * 16 + 16384 : nullptr;

@@ -208,7 +208,8 @@ struct FfnArgs {
   const float* beta;
   unsigned char* out;          // output image [rows128][d/32] (must not alias aimg)
   unsigned out_bytes;          // its size (stores beyond it are dropped)
-  int panels;                  // passes of 128 rows
+  int panels;                  // passes of 128 rows (upper bound)
+  const int* dims;             // null, or device {rows, rows rounded up to 128}: passes beyond them are skipped
   float up_scale;              // 1 / (scale of aimg * scale of the first dense's weights)
   float g_scale;               // scale of the intermediate's hi / lo images (a power of two)
   float down_scale;            // 1 / (g_scale * scale of the second dense's weights)

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
 // this group's second dense)
 #define FD_STAMP_G(i) do { if (PROF) { if (rec && slot == 0 && G == 1 && lane == 0) stp[15 * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
-  if ((int)blockIdx.x >= p.panels) return;
+  // (packed rows: the host knows an upper bound of the row count only; the count itself is in device memory)
+  const int n_pass = p.dims ? min(p.panels, __builtin_amdgcn_readfirstlane(p.dims[1]) >> 7) : p.panels;
+  if ((int)blockIdx.x >= n_pass) return;
   const float os_up = p.up_scale, os_dn = p.down_scale, hs = 0.5f * p.g_scale;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 Y[2 * NKT];  // second dense: out tile T = 2 kt + j, row i = output feature 32 kt + 8 (i / 4) + 4 j + (i % 4)
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     });
   };
 
-  for (int panel = blockIdx.x; panel < p.panels; panel += (int)gridDim.x) {
+  for (int panel = blockIdx.x; panel < n_pass; panel += (int)gridDim.x) {
     FD_STAMP(0);
     if constexpr (TAIL) {
       // ================================================ BertSelfOutput: dense on the context + bias + residual, LayerNorm

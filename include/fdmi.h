@@ -35,7 +35,7 @@ extern "C" {
  *    padding of packed rows is zeroed; head sizes other than 32 (multiples of 32) are accepted */
 /* 3: fd_shift_trim_dev, fd_test_wrap, option "fuse_attn" (round 5) */
 /* 4: fd_fused_attn_supported; option "fuse_attn" takes 2 (the round-5 kernel) and its default kernel no longer promises the bits of
- *    the two-kernel path (round 6) */
+ *    the two-kernel path; option "fuse_ffn" (round 6) */
 #define FDMI_ABI_VERSION 4
 
 enum {
@@ -130,6 +130,12 @@ void fd_destroy(fd_model* m);
  *                96 < L <= 128; kept for A/B measurements).  Every choice meets the same tolerance against the reference
  *                (1e-5 on the forward, 1e-3 rad on a step); 0 and 2 give the same bits as each other, 1 does not (it sums in
  *                another order).
+ *   "fuse_ffn"   FD_PREC_F16X3, d_model 384 / 192 with intermediate size 2 d_model: the tail of a BertLayer (modelling.py:473-480 -> HF
+ *                BertLayer.forward behind the attention) as ONE kernel over passes of 128 token rows.  2: BertSelfOutput (dense +
+ *                residual + LayerNorm), BertIntermediate (dense + GELU) and BertOutput (dense + residual + LayerNorm); neither the
+ *                attention block's output nor the intermediate reaches HBM.  1: the feed-forward pair only.  0: never (three GEMM
+ *                launches).  -1 (default): 2 when the passes fill whole rounds of the device's CUs.  Every choice meets the same
+ *                tolerance against the reference; 1 and 2 sum in another order than 0 (not the same bits).
  *   "split_qkv"  FD_PREC_F16X3: 1 = project q | k and v^T in two launches even when n_heads % 6 == 0 would allow one
  *                (A/B measurements, tests); 0 (default).
  *   "debug_stop" n > 0: a step returns after its first n launches (FD_PREC_F16X3; stage-by-stage comparison with
