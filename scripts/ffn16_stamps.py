@@ -6,7 +6,7 @@ import os
 import sys
 
 os.environ["FDMI_STAMPS"] = "1"
-os.environ.setdefault("FDMI_FUSE_FFN", "1")
+os.environ.setdefault("FDMI_FUSE_FFN", "2")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402

@@ -13,7 +13,7 @@ for set in "${SETS[@]}"; do
   tail -1 $R/$OUT/sq_$i.log | cut -c1-160
 done
 cd $R
-for j in $(seq 1 $i); do python scripts/pmc_summary.py $OUT/sq_$j 2>&1 | grep -E "gemm_img|attn_img|embed_img|head_update_img|^#" | grep -v kernel_stats | cut -c1-170; done | tee $OUT/sq_summary.txt
+for j in $(seq 1 $i); do python scripts/pmc_summary.py $OUT/sq_$j 2>&1 | grep -E "gemm_img|attn_img|seq_attn|ffn16|embed_img|head_update_img|^#" | grep -v kernel_stats | cut -c1-170; done | tee $OUT/sq_summary.txt
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*.db" -delete
 echo "== done"
