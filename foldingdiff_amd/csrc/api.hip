@@ -95,6 +95,7 @@ struct Workspace {
   int graph_varlen = -1;   // ... and the row mode (packed rows launch the slice-capable GEMM instantiation)
   int graph_fuse_attn = -2;  // ... and the fused projection + attention choice
   int graph_fuse_ffn = -2;   // ... and the fused feed-forward choice
+  int graph_rows_hint = -1;  // ... and the row count the launch-sequence choices were made for
   uint64_t last_use = 0;
   void release() {
     if (graph) (void)hipGraphExecDestroy(graph);
@@ -147,6 +148,8 @@ struct fd_model {
                      // 97 .. 128 positions), 0 never, 1 wherever the kernel applies (packed rows too)
   int fuse_ffn = -1;   // row-image path: BertIntermediate + BertOutput as ONE kernel (ffn16.hip): -1 auto (whole rounds of 128-row passes: 2),
                      // 0 never, 1 wherever the kernel applies, 2 with BertSelfOutput in front of it in the same launch
+  int rows_hint = 0;   // packed rows: the caller's exact count of token rows of the next calls (sum of the lengths rounded up to 8), or 0 = unknown;
+                     // the auto choices of the fused kernels then go by it instead of the bound B * ceil8(L) (the count itself lives in device memory)
   // workspaces (buffers + captured graph) are kept per (B, L): sample_length()-driven sampling and ragged chunks
   // alternate between a few shapes
   std::vector<Workspace> cache;
@@ -904,7 +907,9 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
     const int fuse_ffn = m->fuse_ffn >= 0 ? m->fuse_ffn : fuse_ffn_env;
     bool ffn_auto = false;
     {
-      const int ncu = gemm_img_grid(1 << 30, 384), passes = max_rows / 128;
+      // (packed rows: by the caller's row count when it gave one -- the bound B * ceil8(L) overstates ragged batches)
+      const int rows_known = m->varlen && m->rows_hint > 0 && m->rows_hint <= max_rows ? m->rows_hint : max_rows;
+      const int ncu = gemm_img_grid(1 << 30, 384), passes = (rows_known + 127) / 128;
       const int rounds = (passes + ncu - 1) / ncu;
       ffn_auto = (double)passes >= 0.94 * (double)rounds * ncu;
     }
@@ -1059,7 +1064,8 @@ int check_lens(const int32_t* lens, int B, int L) {
 
 // the workspace's captured graph still holds the launch sequence the model's options ask for
 static bool graph_current(const fd_model* m, const Workspace& w) {
-  return w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn && w.graph_fuse_ffn == m->fuse_ffn;
+  return w.graph && w.graph_fuse_ln == m->fuse_ln && w.graph_varlen == m->varlen && w.graph_fuse_attn == m->fuse_attn && w.graph_fuse_ffn == m->fuse_ffn &&
+         w.graph_rows_hint == m->rows_hint;
 }
 
 int ensure_graph(fd_model* m) {
@@ -1096,6 +1102,7 @@ int ensure_graph(fd_model* m) {
   w.graph_varlen = m->varlen;
   w.graph_fuse_attn = m->fuse_attn;
   w.graph_fuse_ffn = m->fuse_ffn;
+  w.graph_rows_hint = m->rows_hint;
   return FD_OK;
 }
 
@@ -1523,6 +1530,7 @@ int fd_set_option(fd_model* m, const char* name, int value) {
   else if (n == "varlen") m->varlen = value ? 1 : 0;
   else if (n == "fuse_attn") m->fuse_attn = value < 0 ? -1 : (value > 2 ? 1 : value);
   else if (n == "fuse_ffn") m->fuse_ffn = value < 0 ? -1 : (value > 2 ? 2 : value);
+  else if (n == "rows_hint") m->rows_hint = value < 0 ? 0 : value;
   else if (n == "split_qkv") {
     m->split_qkv = value ? 1 : 0;
     drop_workspaces(m);  // captured graphs hold the other launch sequence

@@ -463,6 +463,8 @@ def sample(
         if hi > lo:
             prev_varlen = model.set_option("varlen", 1)
             try:
+                if on_gpu:   # the exact row count of this slice: the library's automatic kernel choices go by it (fd_set_option)
+                    model.set_option("rows_hint", sum((int(l) + 7) // 8 * 8 for l in these[lo:hi]))
                 traj = p_sample_loop(
                     model=model, lengths=these[lo:hi], noise=noise[lo:hi], timesteps=T,
                     betas=train_dset.alpha_beta_terms["betas"], is_angle=train_dset.feature_is_angular[feature_key],
@@ -476,6 +478,8 @@ def sample(
                     raise
                 local_error = e
             finally:
+                if on_gpu:
+                    model.set_option("rows_hint", 0)
                 model.set_option("varlen", prev_varlen if prev_varlen is not None else 0)
         elif NOISE_MODE == "torch":  # an empty shard still advances the generator exactly as the other ranks do
             _StepNoise(T - 1, (B, L, F), (0, 0)).materialize()

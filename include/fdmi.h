@@ -136,6 +136,9 @@ void fd_destroy(fd_model* m);
  *                attention block's output nor the intermediate reaches HBM.  1: the feed-forward pair only.  0: never (three GEMM
  *                launches).  -1 (default): 2 when the passes fill whole rounds of the device's CUs.  Every choice meets the same
  *                tolerance against the reference; 1 and 2 sum in another order than 0 (not the same bits).
+ *   "rows_hint"  with "varlen" 1: the exact number of token rows of the next sampling calls (sum over the batch of the lengths rounded up
+ *                to 8; the library itself only has the lengths in device memory and the bound B * ceil8(L)), 0 (default) = unknown.
+ *                It only steers the automatic kernel choices ("fuse_ffn" -1); results are within the same tolerances either way.
  *   "split_qkv"  FD_PREC_F16X3: 1 = project q | k and v^T in two launches even when n_heads % 6 == 0 would allow one
  *                (A/B measurements, tests); 0 (default).
  *   "debug_stop" n > 0: a step returns after its first n launches (FD_PREC_F16X3; stage-by-stage comparison with

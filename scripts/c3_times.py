@@ -22,12 +22,17 @@ betas = beta_schedules.cosine_beta_schedule(1000)
 h = model.prepare(betas)
 lib = _binding.load()
 lengths = [l for l in range(50, 128) for _ in range(10)]
-chunks = {"c3 chunk 0": lengths[:512], "c3 chunk 1": lengths[512:], "c3 merged": lengths, "c3 merged sorted desc": lengths[::-1], "c2": [128] * 512, "c5": [128] * 64, "b8": [128] * 8}
+chunks = {"c3 chunk 0": lengths[:512], "c3 chunk 1": lengths[512:], "c3 chunk 0, run of whole rounds": lengths[:437], "c3 chunk 0, rest": lengths[437:512],
+          "c3 merged": lengths, "c2": [128] * 512, "c2 half": [128] * 256, "b8": [128] * 8}
+if os.environ.get("ONLY"):
+    chunks = {k: v for k, v in chunks.items() if any(o in k for o in os.environ["ONLY"].split(","))}
+hint = int(os.environ.get("ROWS_HINT", 1))   # 1: tell the library the exact row count of a packed run (as sampling.sample does)
 tag = os.environ.get("TAG", "")
 for name, these in chunks.items():
     B, L = len(these), max(these)
     packed = 0 if name in ("c2", "c5", "b8") else 1
     model.set_option("varlen", packed)
+    model.set_option("rows_hint", sum((l + 7) // 8 * 8 for l in these) if packed and hint else 0)
     x = torch.randn(B, L, 6, device="cuda:0")
     lens = torch.tensor(these, dtype=torch.int32, device="cuda:0")
     sampling.sample_on_device(model, x, lens, betas, seed=1, t_start=1)
@@ -47,3 +52,4 @@ for name, these in chunks.items():
     print(f"{tag} {name}: B={B} L={L} tokens={tokens} rows={rows} panels={-(-rows // 128)} " + " ".join(out)
           + f" | step={tot:.3f} ms  {tokens / tot / 1e3:.2f} useful tokens/us")
 model.set_option("varlen", 0)
+model.set_option("rows_hint", 0)

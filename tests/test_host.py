@@ -670,3 +670,4 @@ def test_fused_attention_weight_image_matches_the_fragment_reads():
                                 got = stage[byte // 2: byte // 2 + 8]
                                 want = [(plane, j * d + 32 * h + l31, 32 * kt + 16 * c + 8 * half + e) for e in range(8)]
                                 assert got == want, (d, h, kt, j, l31, half, unit)
+
