@@ -671,3 +671,192 @@ def test_fused_attention_weight_image_matches_the_fragment_reads():
                                 want = [(plane, j * d + 32 * h + l31, 32 * kt + 16 * c + 8 * half + e) for e in range(8)]
                                 assert got == want, (d, h, kt, j, l31, half, unit)
 
+
+
+@pytest.mark.parametrize("nkt,tail,passes", [(12, 1, 2), (12, 0, 2), (6, 1, 3), (6, 0, 1)])
+def test_layer_tail_stream_protocol_and_weight_order(nkt, tail, passes):
+    """ffn::ffn16_kernel (ffn16.hip), its vector-memory protocol and its weight stream restated and simulated for one wave.
+    (1) The stream is ONE sequence of 16 KiB stages (two steps of four 2 KiB tiles) in consumption order: attention.output.dense
+    (TAIL: NKT^2 / 2 steps) | up(0) | up(1) down(0) | ... | up(NG - 1) down(NG - 2) | down(NG - 1); every block is a whole number of
+    turns of the 3-slot ring, so a step's fragment address is a compile-time constant -- checked against the kernel's step order and
+    against upload_ffn16_weights' placement formulas.  (2) vmcnt retires in issue order: `s_waitcnt vmcnt(2)` at the stage top inside the
+    last step of stage n must cover the two pieces of stage n + 1 and nothing more than needed; the request issued there (stage n + 3)
+    lands in the slot of stage n, whose last fragment reads precede the top.  (3) At a pass's end everything is drained once
+    (vmcnt(0): the next rows, the stores, two stages in flight)."""
+    src = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "ffn16.hip")).read()
+    api = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "api.hip")).read()
+    for stmt in ("constexpr int SPS = 2;", "constexpr int NST = 3;", "constexpr int STEP = 4 * TILE;", "FD_WAIT_VM(PPW);",
+                 "FD_WAIT_VM(3 * PPW);  // the rows landed", "FD_WAIT_VM(2 * PPW);  // ... and stage 0",
+                 "constexpr bool top = s % SPS == SPS - 1;", "constexpr int NSA = TAIL ? NKT * NKT / 2 : 0;",
+                 "steps(IC<0>{}, IC<NSA>{}, IC<2>{}, 0u);", "steps(IC<0>{}, IC<NKT>{}, IC<1>{}, abq);", "steps(IC<NKT>{}, IC<SPG>{}, IC<0>{}, 0u);",
+                 "constexpr unsigned off = (unsigned)(((s / SPS) % NST) * STAGE + (s % SPS) * STEP + lo * 1024);"):
+        assert stmt in src, stmt
+    for stmt in ("auto up_at = [&](int G) { return G == 0 ? 0 : nkt + (G - 1) * spg; };",
+                 "auto down_at = [&](int G) { return G == ng - 1 ? nkt + (ng - 1) * spg : nkt + G * spg + nkt; };",
+                 "uint16_t* tile = timg.data() + ((size_t)(kt * (nkt / 2) + T / 4) * 4 + T % 4) * 1024;"):
+        assert stmt in api, stmt
+    NG, SPG, SPS, NST, PPW = nkt, 2 * nkt, 2, 3, 2
+    nsa = nkt * nkt // 2 if tail else 0
+    # ---- (1) the order in which the kernel consumes steps within a pass, as (block, local step): what the stream must hold
+    consumed = [("ao", s) for s in range(nsa)] + [("up", 0, s) for s in range(nkt)]
+    for G in range(NG):
+        if G + 1 < NG:
+            consumed += [("up", G + 1, s) for s in range(nkt)]
+        consumed += [("down", G, s) for s in range(nkt)]
+    up_at = lambda G: 0 if G == 0 else nkt + (G - 1) * SPG                      # noqa: E731  (api.hip)
+    down_at = lambda G: nkt + (NG - 1) * SPG if G == NG - 1 else nkt + G * SPG + nkt   # noqa: E731
+    placed = {}
+    for kt in range(nkt if tail else 0):
+        for T in range(2 * nkt):
+            placed[kt * (nkt // 2) + T // 4] = ("ao", kt * (nkt // 2) + T // 4)
+    for G in range(NG):
+        for ks in range(nkt):
+            placed[nsa + up_at(G) + ks] = ("up", G, ks)
+        for pr in range(2):
+            for T in range(2 * nkt):
+                placed[nsa + down_at(G) + pr * (nkt // 2) + T // 4] = ("down", G, pr * (nkt // 2) + T // 4)
+    assert [placed[i] for i in range(len(consumed))] == consumed and len(placed) == len(consumed) == nsa + NG * SPG
+    # every block starts at ring slot 0 (its fragment addresses use the LOCAL step index)
+    pos = 0
+    for blk_len in ([nsa] if tail else []) + [nkt] * (2 * NG):
+        assert (pos // SPS) % NST == 0 and blk_len % (SPS * NST) == 0, (pos, blk_len)
+        pos += blk_len
+    # ---- (2), (3) one wave's vector-memory queue: the operations still in flight, oldest first; vmcnt(n) retires all but the n youngest
+    n_stage_pass = len(consumed) // SPS
+    q, issued = [], [0]
+
+    def issue_w():
+        q.extend([("w", issued[0])] * PPW)
+        issued[0] += 1
+
+    def wait_vm(n):
+        del q[:max(0, len(q) - n)]
+
+    q.extend([("rows",)] * (2 * nkt + (2 * nkt if tail else 0)))
+    for _ in range(3):
+        issue_w()
+    wait_vm(3 * PPW)
+    assert ("rows",) not in q                      # "the rows landed" (then their lo plane is written to LDS)
+    wait_vm(2 * PPW)
+    assert ("w", 0) not in q and ("w", 1) in q      # "... and stage 0"; stages 1, 2 may still be in flight
+    stage = 0
+    for p in range(passes):
+        for st in range(n_stage_pass):
+            # inside the last step of stage `stage`: FD_WAIT_VM(PPW), barrier, request stage + 3 into the slot of `stage`
+            if ("w", stage + 1) in q:
+                younger = len(q) - 1 - max(i for i, o in enumerate(q) if o == ("w", stage + 1))
+                assert younger == PPW and all(o == ("w", stage + 2) for o in q[-PPW:]), (p, st, q)   # the count is exact: it waits for no more
+            wait_vm(PPW)
+            assert ("w", stage + 1) not in q, (p, st)
+            assert issued[0] == stage + 3 and (stage + 3) % NST == stage % NST   # the request overwrites the slot whose reads are done
+            issue_w()
+            stage += 1
+        q.extend([("rows_next",)] * nkt + [("store",), ("store",), ("lo_next",)] * nkt)
+        wait_vm(0)   # once per pass: the next rows, the stores, and with them the two stages in flight
+    assert issued[0] == passes * n_stage_pass + 3
+
+
+def test_layer_tail_weight_stream_and_register_layouts_compose():
+    """The layout contract of ffn16.hip, emulated lane by lane in numpy (values in float64, no hi / lo split: the split is orthogonal):
+    api.hip's upload_ffn16_weights places the PERMUTED weight rows in the stream; the kernel reads a tile's A operand as lane (c, g) <- unit g,
+    row c; v_mfma_f32_16x16x32_f16 computes D[i][j] = sum_k A[i][k] B[k][j] with A[i][k] in lane i + 16 (k / 8), B[k][j] in lane
+    j + 16 (k / 8), D[i][j] in lane j + 16 (i / 4), register i % 4 (scripts/probes/mfma16_layout_probe.hip).  With the permutation, what a lane
+    holds after a contraction is EXACTLY its operand unit of the next one: attention.output.dense -> (LayerNorm) -> first dense -> (GELU) ->
+    second dense -> output image units, with no cross-lane movement.  The emulation follows the kernel's step order and must reproduce
+    x -> ((x Wo^T) Wi^T) Wd^T (activations left out: they are elementwise in this layout)."""
+    api = open(os.path.join(os.path.dirname(__file__), "..", "foldingdiff_amd", "csrc", "api.hip")).read()
+    for stmt in ("const int f = 64 * G + 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);",
+                 "const int o = 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3);",
+                 "put(down_at(G) + pr * (nkt / 2) + T / 4, T % 4, i, rd.data() + ((size_t)o * nkd + 2 * G + pr) * 64);",
+                 "put(up_at(G) + ks, t, i, ri.data() + ((size_t)f * nkt + ks) * 64);"):
+        assert stmt in api, stmt
+    nkt = 2                                  # d_model 64, intermediate 128: the formulas do not depend on the size
+    d, ff, NG, SPG = 32 * nkt, 64 * nkt, nkt, 2 * nkt
+    rng = np.random.RandomState(0)
+    Wo, Wi, Wd = rng.randn(d, d), rng.randn(ff, d), rng.randn(d, ff)
+    x = rng.randn(16, d)                     # one wave's sixteen token rows
+    # ---- the stream: tiles [step][t] of (16 rows, 32 k), rows permuted (api.hip)
+    nsa = nkt * nkt // 2
+    stream = np.zeros((nsa + NG * SPG, 4, 16, 32))
+    up_at = lambda G: 0 if G == 0 else nkt + (G - 1) * SPG                      # noqa: E731
+    down_at = lambda G: nkt + (NG - 1) * SPG if G == NG - 1 else nkt + G * SPG + nkt   # noqa: E731
+    for kt in range(nkt):
+        for T in range(2 * nkt):
+            for i in range(16):
+                o = 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3)
+                stream[kt * (nkt // 2) + T // 4, T % 4, i] = Wo[o, 32 * kt:32 * kt + 32]
+    for G in range(NG):
+        for ks in range(nkt):
+            for t in range(4):
+                for i in range(16):
+                    f = 64 * G + 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3)
+                    stream[nsa + up_at(G) + ks, t, i] = Wi[f, 32 * ks:32 * ks + 32]
+        for pr in range(2):
+            for T in range(2 * nkt):
+                for i in range(16):
+                    o = 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3)
+                    stream[nsa + down_at(G) + pr * (nkt // 2) + T // 4, T % 4, i] = Wd[o, 64 * G + 32 * pr:64 * G + 32 * pr + 32]
+
+    def mfma(tile, breg, acc):
+        """acc[lane][reg] += D, A = tile rows (lane (c, g) reads row c, k 8 g .. 8 g + 7), B = breg[lane][8]: lane (c, g) holds k 8 g .. of token c"""
+        B = np.zeros((32, 16))
+        for lane in range(64):
+            c, g = lane & 15, lane >> 4
+            B[8 * g:8 * g + 8, c] = breg[lane]
+        D = tile @ B
+        for i in range(16):
+            for j in range(16):
+                acc[j + 16 * (i // 4), i % 4] += D[i, j]
+
+    def operand(rows, kt):   # the stationary operand registers of k32 step kt: lane (c, g) <- features 32 kt + 8 g .. + 7 of token c
+        return np.array([rows[lane & 15, 32 * kt + 8 * (lane >> 4):32 * kt + 8 * (lane >> 4) + 8] for lane in range(64)])
+
+    def to_operands(acc_tiles):   # accumulator tiles (2 kt, 2 kt + 1) -> the operand registers of k32 step kt, WITHOUT leaving the lane
+        return [np.concatenate([acc_tiles[2 * kt], acc_tiles[2 * kt + 1]], axis=1) for kt in range(len(acc_tiles) // 2)]
+
+    step = [0]
+
+    def next_step():
+        step[0] += 1
+        return stream[step[0] - 1]
+
+    # attention.output.dense on the context rows: k32 step kt, output tiles 4 q .. 4 q + 3
+    Y = [np.zeros((64, 4)) for _ in range(2 * nkt)]
+    for kt in range(nkt):
+        for q in range(nkt // 2):
+            tiles = next_step()
+            for t in range(4):
+                mfma(tiles[t], operand(x, kt), Y[4 * q + t])
+    a_ops = to_operands(Y)                                  # its output IS the next stationary operand
+    want_a = x @ Wo.T
+    for kt in range(nkt):
+        assert np.allclose(a_ops[kt], operand(want_a, kt))
+    # the feed-forward in the kernel's order: up(0) | up(1) down(0) | ... | down(NG - 1)
+    Y = [np.zeros((64, 4)) for _ in range(2 * nkt)]
+
+    def up():
+        U = [np.zeros((64, 4)) for _ in range(4)]
+        for ks in range(nkt):
+            tiles = next_step()
+            for t in range(4):
+                mfma(tiles[t], a_ops[ks], U[t])
+        return U
+
+    def down(U):
+        u_ops = to_operands(U)                              # (the GELU and the split happen here, per register)
+        for pr in range(2):
+            for q in range(nkt // 2):
+                tiles = next_step()
+                for t in range(4):
+                    mfma(tiles[t], u_ops[pr], Y[4 * q + t])
+
+    U = up()
+    for G in range(NG):
+        Un = up() if G + 1 < NG else None
+        down(U)
+        U = Un
+    assert step[0] == len(stream)
+    want = (want_a @ Wi.T) @ Wd.T
+    out_ops = to_operands(Y)                                # = the units of the output image, and of the residual's registers
+    for kt in range(nkt):
+        assert np.allclose(out_ops[kt], operand(want, kt))
