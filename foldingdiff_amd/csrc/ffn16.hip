@@ -256,11 +256,7 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
     constexpr int s0 = decltype(S0)::value, s1 = decltype(S1)::value;
     constexpr bool gel = decltype(GEL)::value == 1, pha = decltype(GEL)::value == 2;
     auto stage_top = [&]() __attribute__((always_inline)) {
-#ifdef FDMI_FFN_SAFE  // debug build: no counted wait
-      FD_WAIT_VM(0);
-#else
       FD_WAIT_VM(PPW);
-#endif
       barrier_keep_vm();
       issue_w();
     };
@@ -318,13 +314,7 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
       plane_reads(S, IC<1>{}, fy);
       FD_SB();
       if constexpr (top) {
-#if defined(FDMI_FFN_SAMETOP)
-        stage_top();
-#elif defined(FDMI_FFN_SWAPTOP)
-        if (grp != 0) stage_top();
-#elif !defined(FDMI_FFN_LATETOP)
         if (grp == 0) stage_top();
-#endif
       }
 #if FDMI_FFN_PRIO
       __builtin_amdgcn_s_setprio(FDMI_FFN_PRIO);
@@ -335,27 +325,16 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
       __builtin_amdgcn_s_setprio(0);
 #endif
       FD_SB();
-#if defined(FDMI_FFN_LATETOP)
-      if constexpr (top) stage_top();
-#elif defined(FDMI_FFN_SWAPTOP)
       if constexpr (top) {
-        if (grp == 0) stage_top();
-      }
-#elif !defined(FDMI_FFN_SAMETOP)
-      if constexpr (top) {
-#ifdef FDMI_FFN_NOPS
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
-#endif
         if (grp != 0) stage_top();
       }
-#endif
       if constexpr (s + 1 < s1) plane_reads(IC<s + 1>{}, IC<0>{}, fx);
       FD_SB();
       if constexpr (gel) {
-        // the previous group's GELU, an eighth at a time in the steps 1 .. NKT - 2 of this group's first dense.  The two waves of a
-        // SIMD run it at DIFFERENT places of the step: in the same place both would leave the matrix pipe at the same time (measured:
-        // the step then costs its matrix time PLUS both waves' vector time, 758 against 567 cycles).  Group 0: here, beside the
-        // lo-plane instructions of group 1
+        // the previous group's GELU, an eighth at a time in the steps 1 .. NKT - 2 of this group's first dense; group 0 here (beside
+        // the lo-plane instructions of group 1), group 1 at the step's end.  (Measured: at the same place or at different ones, inside the
+        // first dense or on its own in front of it, a group costs the same 15.4-15.6 k cycles -- with 16 x 16 x 32 MFMAs the vector time
+        // adds to the matrix time, profiles/r06_ffn16_notes.log.  The arrangement stays for the day fragments can be requested further ahead.)
         if (grp == 0) {
           static_for<0, 8>([&](auto P) __attribute__((always_inline)) {
             if constexpr (1 + decltype(P)::value * (NKT - 2) / 8 == s) gelu_piece(P, abq);
