@@ -1,29 +1,33 @@
-// BertIntermediate + BertOutput of 128 token rows in ONE kernel: dense (d -> 2 d) + exact-erf GELU + dense (2 d -> d) + residual +
-// LayerNorm (HF 4.11.3 BertIntermediate / BertOutput inside BertLayer.feed_forward_chunk; the encoder is constructed at
-// foldingdiff/modelling.py:271 and called at :473-480).  The 768-wide intermediate never reaches HBM: per layer 201 MB less written
-// and 201 MB less read at BASELINE C2 (40 % of the layer's stored bytes; the step is bound by what the chip can store and, with
-// clocks at ~1.9 of 2.4 GHz under the 1400 W cap, by what it burns: profiles/r06_power_probe.log).
+// The tail of a BertLayer for 128 token rows in ONE kernel (HF 4.11.3 BertLayer.forward behind the attention: BertSelfOutput,
+// BertIntermediate, BertOutput; the encoder is constructed at foldingdiff/modelling.py:271 and called at :473-480):
+//   TAIL   attention.output.dense + bias + residual (the layer's input rows) + LayerNorm                 (BertSelfOutput)
+//          intermediate.dense + bias + exact-erf GELU                                                     (BertIntermediate)
+//          output.dense + bias + residual (BertSelfOutput's output) + LayerNorm                           (BertOutput)
+// Neither BertSelfOutput's output nor the 2 d wide intermediate reaches HBM: 604 MB less traffic per layer at BASELINE C2.  The step is
+// bound by what the chip can store and, with the shader clock at 1.8-2.1 of 2.4 GHz under the 1400 W cap, by what it burns
+// (profiles/r06_power_probe.log); same box, sustained: 74.7 -> 83.4 backbones/s (profiles/r06_ffn16_notes.log).
 //
-// The structure is seq_attn16.hip's projection, twice over: a wave owns SIXTEEN token rows, two waves per SIMD, 256 registers each,
+// The structure is seq_attn16.hip's projection, three times over: a wave owns SIXTEEN token rows, two waves per SIMD, 256 registers each,
 // every contraction on v_mfma_f32_16x16x32_f16 in the swapped form D^T = W x^T (a lane owns a token):
-//   * the rows' input image (BertSelfOutput's LayerNorm output, hi / lo fp16) is stationary: the hi plane in 48 registers, the lo plane
-//     in LDS (96 KiB per 128 rows, lane-linear per wave: read back as the B operand w_hi x_lo needs, one 16-byte read per
-//     step -- with both planes in registers hipcc spills the image and reloads it behind vmcnt(0) in every
-//     group); B operand of the first dense AND the residual of the second, whose 16 x d output accumulates in 96 registers over
-//     the whole pass;
-//   * the intermediate is produced 64 features (four 16 x 16 tiles) at a time: bias, GELU and the hi / lo split in registers; the weight
-//     rows are PERMUTED in the stream (tile j of a pair, row i = feature 8 (i / 4) + 4 j + (i % 4)) so that the C/D layout hands a lane
-//     eight consecutive features of its token = one 16-byte B-operand unit of the second dense, whose own output rows are permuted
-//     the same way (= the units of the output image, and of the stationary input image for the residual): no cross-lane traffic;
-//   * both weight matrices arrive as ONE linear stream of 16 KiB stages in consumption order (per 64-feature group: 6 stages of the
-//     first dense, 6 of the second, the first dense one group ahead: its neighbour's GELU runs inside it; 144 stages = 2.25 MiB per pass at d_model 384) through a 3-slot LDS ring: LDS-DMA, two 1 KiB
-//     pieces per wave and stage, one workgroup barrier per stage, counted s_waitcnt vmcnt (the stream never drains inside a pass
-//     and does not stop at a pass's end); a group is a whole number of ring turns, so every fragment address is an immediate;
+//   * the rows' operand image (hi / lo fp16) is stationary: the hi plane in 48 registers, the lo plane in LDS (96 KiB per 128 rows, each
+//     wave its own rows, lane-linear: read back as the B operand w_hi x_lo needs, one 16-byte read per step -- with both planes in
+//     registers hipcc spills the image and reloads it behind vmcnt(0) in every group); B operand of a dense AND the residual of the next
+//     one; a dense's 16 x d output accumulates in 96 registers;
+//   * the weight rows are PERMUTED in the stream (tile j of a pair, row i = feature 8 (i / 4) + 4 j + (i % 4)) so that the C/D layout hands a
+//     lane eight consecutive features of its token = one 16-byte B-operand unit of the next dense, and one unit of the row images: no
+//     cross-lane traffic anywhere.  BertSelfOutput's LayerNorm output therefore IS the stationary operand of the first dense (hi halves
+//     into the context's registers, lo halves into its LDS rows); the intermediate is produced 64 features (four 16 x 16 tiles) at a
+//     time -- bias, GELU and the hi / lo split in registers -- as the B operand pairs of the second dense;
+//   * the three weight matrices arrive as ONE linear stream of 16 KiB stages in consumption order -- attention.output.dense (36 stages at
+//     d_model 384), then per 64-feature group 6 stages of the first dense and 6 of the second, the first dense one group ahead (its
+//     neighbour's GELU runs inside it): 180 stages = 2.8 MiB per pass -- through a 3-slot LDS ring: LDS-DMA, two 1 KiB pieces per wave and
+//     stage, one workgroup barrier per stage, counted s_waitcnt vmcnt (the stream never drains inside a pass and does not stop at a
+//     pass's end); every block is a whole number of ring turns, so every fragment address is an immediate;
 //   * a step = four weight tiles against one B operand pair: 8 fragment reads and 12 MFMAs (w_hi x_hi | w_hi x_lo | w_lo x_hi), the
 //     next plane requested while the current one multiplies.
-// LayerNorm: a row's 384 outputs sit in the four lanes (c, g = 0..3): in-lane sums + two lane-group swaps.
-// Arithmetic: the fp16 hi / lo split triples of gemm_img.hip with K = 32 MFMAs: fp32-class results, not the bits of the two-GEMM path
-// (the oracle gates of tests/test_gpu_parity.py are the contract).
+// LayerNorm: a row's 384 values sit in the four lanes (c, g = 0..3): in-lane sums + two lane-group swaps.
+// Arithmetic: the fp16 hi / lo split triples of gemm_img.hip with K = 32 MFMAs: fp32-class results, not the bits of the GEMM path (the
+// oracle gates of tests/test_gpu_parity.py are the contract; tests/test_host.py emulates the layouts lane by lane).
 #include <cstdlib>
 #include <type_traits>
 
