@@ -913,12 +913,10 @@ int run_step_img(fd_model* m, hipStream_t s, const StepMode& mode) {
       const int rounds = (passes + ncu - 1) / ncu;
       ffn_auto = (double)passes >= 0.94 * (double)rounds * ncu;
     }
-    const bool fused_ffn_any = fuse_ffn != 0 && (fuse_ffn > 0 || ffn_auto) && lw.wff_i.p && ffn16_supported(d, ff) &&
+    const bool fused_ffn = fuse_ffn != 0 && (fuse_ffn > 0 || ffn_auto) && lw.wff_i.p && ffn16_supported(d, ff) &&
                            (size_t)w.cap * d * 4 < (1ull << 32) - 65536;
-    const bool fused_ffn = fused_ffn_any;
     const bool fused_tail = fused_ffn && fuse_ffn != 1 && lw.wtail_i.p && d <= 384;
-    if (!fused_tail)
-    {
+    if (!fused_tail) {
       GemmImgArgs g = base();
       g.A = w.cimg; g.W = static_cast<const unsigned char*>(lw.wo_i.p); g.bias = lw.bo; g.gamma = lw.ln1g; g.beta = lw.ln1b;
       g.resid = w.himg; g.out = w.aimg; g.N = d; g.K = d;
