@@ -72,7 +72,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 #ifndef FDMI_FFN_DBG
 #define FDMI_FFN_DBG 0  // ablation builds (WRONG results): 1 = no GELU arithmetic, 2 = no MFMAs of the second dense, 4 = none of the first,
-                        // 8 = no lo-plane fragment reads (half the LDS traffic)
+                        // 8 = no lo-plane fragment reads (half the LDS traffic), 16 = no output stores
 #endif
 #ifndef FDMI_FFN_ST_AUX
 #define FDMI_FFN_ST_AUX 0  // cache policy bits of the output stores (A/B builds: 2 = nt)
@@ -536,8 +536,13 @@ __global__ __launch_bounds__(64 * NW) void ffn16_kernel(FfnArgs p) {
           hv[j] = a;
           lv[j] = b;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(hv, rs_o, (int)ooff, kt * 8 * 512, FDMI_FFN_ST_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(lv, rs_o, (int)ooff, (kt * 8 + 4) * 512, FDMI_FFN_ST_AUX);
+#if FDMI_FFN_DBG & 16
+        if (hv[0] == 0x12345678u && lv[1] == 0x9abcdef0u)   // (the values stay needed; practically never stored)
+#endif
+        {
+          __builtin_amdgcn_raw_buffer_store_b128(hv, rs_o, (int)ooff, kt * 8 * 512, FDMI_FFN_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(lv, rs_o, (int)ooff, (kt * 8 + 4) * 512, FDMI_FFN_ST_AUX);
+        }
         load_lo(KT, noff);  // (unconditionally: beyond the last pass the rows read as zeros and are never used)
         if constexpr (TAIL) load_res(KT, noff, Y);
         FD_SB();
